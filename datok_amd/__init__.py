@@ -1,0 +1,21 @@
+"""datok_amd -- MI355X-native batch finite-state tokenizer, drop-in for the hot
+path of KorAP/Datok (LoadTokenizerFile / Tokenizer.TransduceTokenWriter /
+TokenWriter).
+
+Python host mirror of the reference's Go surface; the walk runs in hand-written
+HIP kernels behind the C-ABI of libdatok_gpu.so (include/datok_gpu.h):
+
+    Go (reference)                       here
+    ------------------------------------ -----------------------------------------
+    Bits / TOKENS ... SIMPLE             TOKENS ... SIMPLE        (token_writer.go:17-25)
+    TokenWriter, NewTokenWriter(w, f)    TokenWriter, new_token_writer(w, f)  (token_writer.go:27-175)
+    LoadTokenizerFile(file) Tokenizer    load_tokenizer_file(file) -> Tokenizer | None (fomafile.go:452-484)
+    tok.Transduce(r, w) bool             Tokenizer.transduce(r, w)            (matrix.go:340-342)
+    tok.TransduceTokenWriter(r, tw) bool Tokenizer.transduce_token_writer(r, tw) (matrix.go:348-698)
+    tok.Type() string                    Tokenizer.type()                     (matrix.go:102)
+    --                                   Batch: many documents per launch (addition)
+"""
+from ._lib import (DatokGpuError, ST_BAD_MODEL, ST_EMPTY_TEXT, ST_IRREGULAR, ST_STEP_LIMIT,  # noqa: F401
+                   ST_WINDOW_OVERFLOW, build, lib)
+from .host import (NEWLINE_AFTER_EOT, SENTENCE_POS, SENTENCES, SIMPLE, TOKEN_POS, TOKENS, Batch,  # noqa: F401
+                   BatchResult, TokenWriter, Tokenizer, load_tokenizer_file, new_token_writer, replay)

@@ -1,0 +1,706 @@
+// dtk_host.cpp -- host side of libdatok_gpu.so: model files, device tables,
+// batch plumbing.  Everything that computes runs in dtk_kernels.hip; nothing
+// here walks the automaton.
+#include <hip/hip_runtime.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/datok_gpu.h"
+#include "dtk_internal.h"
+
+// --------------------------------------------------------------- error state
+
+static thread_local std::string g_hip_err;
+
+static int hip_fail(hipError_t e, const char *what) {
+  g_hip_err = std::string(what) + ": " + hipGetErrorString(e);
+  return e == hipErrorNoDevice || e == hipErrorInvalidDevice ? DTK_E_NO_DEVICE : DTK_E_HIP;
+}
+#define HIP_TRY(call)                                   \
+  do {                                                  \
+    hipError_t e_ = (call);                             \
+    if (e_ != hipSuccess) return hip_fail(e_, #call);   \
+  } while (0)
+
+extern "C" const char *dtk_last_hip_error(void) { return g_hip_err.c_str(); }
+
+extern "C" const char *dtk_strerror(int code) {
+  switch (code) {
+    case DTK_OK: return "ok";
+    case DTK_E_IO: return "cannot open or read the tokenizer file";
+    case DTK_E_FORMAT: return "not a gzip'd MATOK/DATOK file (magic, version or length)";
+    case DTK_E_NO_DEVICE: return "no usable HIP device (this library has no CPU path)";
+    case DTK_E_HIP: return "HIP runtime error (see dtk_last_hip_error)";
+    case DTK_E_ARG: return "invalid argument";
+    case DTK_E_MODEL: return "model outside device limits (symbols >= 2048, special ids out of range, epsilon cycle)";
+    case DTK_E_CAPACITY: return "batch exceeds the capacity it was created with";
+    case DTK_E_STATE: return "call out of order";
+    default: return "unknown error";
+  }
+}
+
+extern "C" int dtk_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+extern "C" int dtk_set_device(int device) {
+  HIP_TRY(hipSetDevice(device));
+  return DTK_OK;
+}
+
+// ------------------------------------------------------------------- model
+
+struct dtk_model {
+  int kind = 0;
+  int epsilon = 0, unknown = 0, identity = 0, final_state = 0, sigma_count = 0;
+  uint32_t state_count = 0;
+  uint64_t array_len = 0;
+  uint32_t n_eps_states = 0, max_eps_chain = 0, unknown_used = 0;
+  uint64_t device_bytes = 0;
+  int device = 0;
+  // host copy of the sigma map, for rendering (Go string(rune) of a token surface)
+  std::vector<uint32_t> sigma_runes;
+  std::vector<uint16_t> sigma_syms;
+  uint16_t ascii[256];
+  // device
+  void *d_tab = nullptr;
+  uint16_t *d_ascii = nullptr;
+  uint32_t *d_runes = nullptr;
+  uint16_t *d_syms = nullptr;
+  DtkTableDev tab{};
+  DtkSigmaDev sig{};
+};
+
+// Go unicode/utf8.DecodeRune (host copy, used for the sigma block of the model
+// files, matrix.go:296 / datok.go:687, and for rendering surfaces).
+static int go_decode_host(const uint8_t *p, size_t n, uint32_t *r) {
+  *r = 0xFFFD;
+  if (n == 0) return 0;
+  uint32_t b0 = p[0];
+  if (b0 < 0x80) { *r = b0; return 1; }
+  if (b0 < 0xC2 || b0 > 0xF4) return 1;
+  if (b0 < 0xE0) {
+    if (n < 2 || (p[1] & 0xC0) != 0x80) return 1;
+    *r = ((b0 & 0x1F) << 6) | (p[1] & 0x3F);
+    return 2;
+  }
+  if (b0 < 0xF0) {
+    uint32_t lo = b0 == 0xE0 ? 0xA0 : 0x80, hi = b0 == 0xED ? 0x9F : 0xBF;
+    if (n < 3 || p[1] < lo || p[1] > hi || (p[2] & 0xC0) != 0x80) return 1;
+    *r = ((b0 & 0x0F) << 12) | ((uint32_t)(p[1] & 0x3F) << 6) | (p[2] & 0x3F);
+    return 3;
+  }
+  uint32_t lo = b0 == 0xF0 ? 0x90 : 0x80, hi = b0 == 0xF4 ? 0x8F : 0xBF;
+  if (n < 4 || p[1] < lo || p[1] > hi || (p[2] & 0xC0) != 0x80 || (p[3] & 0xC0) != 0x80) return 1;
+  *r = ((b0 & 0x07) << 18) | ((uint32_t)(p[1] & 0x3F) << 12) | ((uint32_t)(p[2] & 0x3F) << 6) | (p[3] & 0x3F);
+  return 4;
+}
+
+static uint16_t rd16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+static uint32_t rd32(const uint8_t *p) {
+  return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+
+// gzip.NewReader + ReadAll (matrix.go:222, fomafile.go:460)
+static int gunzip(const uint8_t *gz, size_t n, std::vector<uint8_t> &out) {
+  if (n < 18 || gz[0] != 0x1f || gz[1] != 0x8b) return DTK_E_FORMAT;
+  z_stream zs;
+  memset(&zs, 0, sizeof zs);
+  if (inflateInit2(&zs, 16 + MAX_WBITS) != Z_OK) return DTK_E_FORMAT;
+  zs.next_in = const_cast<Bytef *>(gz);
+  zs.avail_in = (uInt)n;
+  out.resize(std::max<size_t>(n * 8, 1 << 16));
+  size_t have = 0;
+  int rc;
+  do {
+    if (have == out.size()) out.resize(out.size() * 2);
+    zs.next_out = out.data() + have;
+    zs.avail_out = (uInt)std::min<size_t>(out.size() - have, 1u << 30);
+    const size_t before = zs.avail_out;
+    rc = inflate(&zs, Z_NO_FLUSH);
+    have += before - zs.avail_out;
+  } while (rc == Z_OK);
+  inflateEnd(&zs);
+  if (rc != Z_STREAM_END) return DTK_E_FORMAT;
+  out.resize(have);
+  return DTK_OK;
+}
+
+// Sigma block: sigmaCount UTF-8 runes, NUL = "no character" (matrix.go:288-303,
+// datok.go:679-694).  A later index overwrites an earlier one, like the Go map.
+static size_t parse_sigma(dtk_model *m, const std::vector<uint8_t> &raw, size_t off) {
+  for (int i = 0; i < 256; i++) m->ascii[i] = (uint16_t)m->identity;
+  std::vector<std::pair<uint32_t, uint16_t>> ent;
+  for (int x = 0; x < m->sigma_count; x++) {
+    if (off >= raw.size()) continue;
+    uint32_t r;
+    int w = go_decode_host(raw.data() + off, raw.size() - off, &r);
+    off += (size_t)w;
+    if (r != 0) {
+      if (r < 256) m->ascii[r] = (uint16_t)x;
+      ent.emplace_back(r, (uint16_t)x);
+    }
+  }
+  std::stable_sort(ent.begin(), ent.end(),
+                   [](const auto &a, const auto &b) { return a.first < b.first; });
+  for (auto &e : ent) {
+    if (!m->sigma_runes.empty() && m->sigma_runes.back() == e.first) m->sigma_syms.back() = e.second;
+    else { m->sigma_runes.push_back(e.first); m->sigma_syms.push_back(e.second); }
+  }
+  return off;
+}
+
+static int upload(dtk_model *m, const void *tab, size_t tab_bytes) {
+  HIP_TRY(hipGetDevice(&m->device));
+  HIP_TRY(hipMalloc(&m->d_tab, std::max<size_t>(tab_bytes, 16)));
+  HIP_TRY(hipMemcpy(m->d_tab, tab, tab_bytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc((void **)&m->d_ascii, 256 * sizeof(uint16_t)));
+  HIP_TRY(hipMemcpy(m->d_ascii, m->ascii, 256 * sizeof(uint16_t), hipMemcpyHostToDevice));
+  const size_t nr = m->sigma_runes.size();
+  HIP_TRY(hipMalloc((void **)&m->d_runes, std::max<size_t>(nr, 1) * sizeof(uint32_t)));
+  HIP_TRY(hipMalloc((void **)&m->d_syms, std::max<size_t>(nr, 1) * sizeof(uint16_t)));
+  if (nr) {
+    HIP_TRY(hipMemcpy(m->d_runes, m->sigma_runes.data(), nr * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(m->d_syms, m->sigma_syms.data(), nr * sizeof(uint16_t), hipMemcpyHostToDevice));
+  }
+  m->device_bytes = tab_bytes + 512 + nr * 6;
+  m->sig.ascii = m->d_ascii;
+  m->sig.runes = m->d_runes;
+  m->sig.syms = m->d_syms;
+  m->sig.n_runes = (uint32_t)nr;
+  m->sig.identity = (uint32_t)m->identity;
+  m->tab.tab = m->d_tab;
+  m->tab.epsilon = (uint32_t)m->epsilon;
+  m->tab.unknown = (uint32_t)m->unknown;
+  m->tab.identity = (uint32_t)m->identity;
+  return DTK_OK;
+}
+
+static bool special_ids_ok(const dtk_model *m) {
+  // The walk compares symbols against these ids; the symbol stream has 11 bits.
+  // identity == unknown makes the retry of matrix.go:478-485 spin forever upstream.
+  return m->sigma_count >= 1 && m->sigma_count <= (int)DTK_SYM_MAX && m->epsilon >= 1 &&
+         m->epsilon < m->sigma_count && m->unknown < m->sigma_count && m->identity < m->sigma_count &&
+         m->identity != m->unknown && m->epsilon != m->identity;
+}
+
+// ParseMatrix (matrix.go:235-337) + device layout.
+static int build_matrix(dtk_model *m, const std::vector<uint8_t> &raw) {
+  if (raw.size() < 19) return DTK_E_FORMAT;
+  const uint8_t *h = raw.data() + 5;
+  if (rd16(h) != 1) return DTK_E_FORMAT;  // VERSION
+  m->kind = DTK_KIND_MATRIX;
+  m->epsilon = rd16(h + 2);
+  m->unknown = rd16(h + 4);
+  m->identity = rd16(h + 6);
+  m->state_count = rd32(h + 8);
+  m->sigma_count = rd16(h + 12);
+  m->array_len = ((uint64_t)m->state_count + 1) * (uint64_t)m->sigma_count;  // matrix.go:286
+  size_t off = parse_sigma(m, raw, 19);
+  if (off >= raw.size() || raw[off] != 'M') return DTK_E_FORMAT;  // matrix.go:305-315
+  off++;
+  if (raw.size() - off < m->array_len * 4) return DTK_E_FORMAT;   // matrix.go:327-330
+  if (!special_ids_ok(m) || m->state_count == 0 || m->state_count >= 0x7FFFFFFFu) return DTK_E_MODEL;
+
+  const uint64_t N = m->state_count, S = (uint64_t)m->sigma_count;
+  const uint8_t *cells = raw.data() + off;
+  auto cell = [&](uint64_t a, uint64_t t) -> uint32_t {  // array[(a-1)*stateCount + t], matrix.go:463
+    return rd32(cells + ((a - 1) * N + t) * 4);
+  };
+
+  // renumber: states with an epsilon arc first (probe of matrix.go:442 -> compare)
+  std::vector<uint32_t> newid(N + 1, 0);
+  uint32_t next = 1;
+  for (uint64_t t = 1; t <= N; t++)
+    if (cell((uint64_t)m->epsilon, t) != 0) newid[t] = next++;
+  m->n_eps_states = next - 1;
+  for (uint64_t t = 1; t <= N; t++)
+    if (newid[t] == 0) newid[t] = next++;
+
+  // epsilon chains: reject cycles (the reference would never return, matrix.go:633-634)
+  {
+    std::vector<uint32_t> depth(N + 1, 0);
+    uint32_t best = 0;
+    for (uint64_t t = 1; t <= N; t++) {
+      uint64_t cur = t;
+      uint32_t len = 0;
+      while (true) {
+        uint32_t nx = cell((uint64_t)m->epsilon, cur) & ~DTK_FIRSTBIT;
+        if (nx == 0 || nx > N) break;
+        len++;
+        if (len > N) return DTK_E_MODEL;
+        cur = nx;
+      }
+      best = std::max(best, len);
+    }
+    m->max_eps_chain = best;
+  }
+
+  const bool wide = (N + 1) > 0x7FFFu;
+  const uint32_t stride = (uint32_t)((S + 7) & ~7ull);
+  const size_t cells_total = (size_t)(N + 1) * stride;
+  std::vector<uint8_t> host(cells_total * (wide ? 4 : 2), 0);
+  for (uint64_t a = 1; a < S; a++) {
+    for (uint64_t t = 1; t <= N; t++) {
+      const uint32_t x = cell(a, t);
+      const uint32_t tgt = x & ~DTK_FIRSTBIT;
+      if (tgt == 0) continue;
+      if (tgt > N) return DTK_E_MODEL;
+      if ((int)a == m->unknown) m->unknown_used = 1;
+      const size_t at = (size_t)newid[t] * stride + a;
+      if (wide) {
+        uint32_t v = newid[tgt] | (x & DTK_FIRSTBIT);
+        memcpy(host.data() + at * 4, &v, 4);
+      } else {
+        uint16_t v = (uint16_t)(newid[tgt] | ((x & DTK_FIRSTBIT) ? 0x8000u : 0u));
+        memcpy(host.data() + at * 2, &v, 2);
+      }
+    }
+  }
+  m->tab.kind = DTK_KIND_MATRIX;
+  m->tab.entry_bytes = wide ? 4 : 2;
+  m->tab.stride = stride;
+  m->tab.n_states = (uint32_t)N;
+  m->tab.n_eps = m->n_eps_states;
+  m->tab.start = newid[1];
+  return upload(m, host.data(), host.size());
+}
+
+// ParseDatok (datok.go:621-729) + device layout.
+static int build_datok(dtk_model *m, const std::vector<uint8_t> &raw) {
+  if (raw.size() < 21) return DTK_E_FORMAT;
+  const uint8_t *h = raw.data() + 5;
+  if (rd16(h) != 1) return DTK_E_FORMAT;
+  m->kind = DTK_KIND_DA;
+  m->epsilon = rd16(h + 2);
+  m->unknown = rd16(h + 4);
+  m->identity = rd16(h + 6);
+  m->final_state = rd16(h + 8);
+  m->sigma_count = rd16(h + 10);
+  m->array_len = rd32(h + 12) / 2;  // "Legacy support", datok.go:674
+  size_t off = parse_sigma(m, raw, 21);
+  if (off >= raw.size() || raw[off] != 'T') return DTK_E_FORMAT;
+  off++;
+  if (raw.size() - off < m->array_len * 8) return DTK_E_FORMAT;
+  if (!special_ids_ok(m) || m->array_len < 2 || m->array_len >= DTK_RESTBIT) return DTK_E_MODEL;
+
+  const uint64_t L = m->array_len;
+  std::vector<uint32_t> bc(L * 2);
+  for (uint64_t i = 0; i < L * 2; i++) bc[i] = rd32(raw.data() + off + i * 4);
+  const uint32_t size = bc[3] & DTK_RESTBIT;  // array[1].check, datok.go:333-335
+  m->state_count = size;
+  auto has_eps = [&](uint64_t s) -> bool {  // datok.go:876
+    const uint64_t ei = (uint64_t)(bc[2 * s] & DTK_RESTBIT) + (uint32_t)m->epsilon;
+    return ei < L && (bc[2 * ei + 1] & DTK_RESTBIT) == s;
+  };
+  // epsilon arc target incl. representative hop (datok.go:889-901, 1056-1058)
+  auto eps_target = [&](uint64_t s) -> uint64_t {
+    const uint64_t ei = (uint64_t)(bc[2 * s] & DTK_RESTBIT) + (uint32_t)m->epsilon;
+    if (ei >= L || ei > size || (bc[2 * ei + 1] & DTK_RESTBIT) != s) return 0;
+    if (bc[2 * ei] & DTK_FIRSTBIT) return bc[2 * ei] & DTK_RESTBIT;
+    return ei;
+  };
+  uint32_t neps = 0, best = 0;
+  for (uint64_t s = 1; s < L; s++) {
+    if (!has_eps(s)) continue;
+    neps++;
+    uint64_t cur = s;
+    uint32_t len = 0;
+    while (true) {
+      uint64_t nx = eps_target(cur);
+      if (nx == 0 || nx >= L) break;
+      len++;
+      if (len > 4096) return DTK_E_MODEL;  // epsilon cycle
+      cur = nx;
+    }
+    best = std::max(best, len);
+  }
+  m->n_eps_states = neps;
+  m->max_eps_chain = best;
+  for (uint64_t i = 1; i < L && i <= size; i++) {
+    const uint64_t par = bc[2 * i + 1] & DTK_RESTBIT;
+    if (par && par < L && (uint64_t)(bc[2 * par] & DTK_RESTBIT) + (uint32_t)m->unknown == i) {
+      m->unknown_used = 1;
+      break;
+    }
+  }
+  std::vector<uint32_t> dev(L * 2);
+  for (uint64_t s = 0; s < L; s++) {
+    dev[2 * s] = (bc[2 * s] & (DTK_FIRSTBIT | DTK_RESTBIT)) | (s >= 1 && has_eps(s) ? DTK_SECONDBIT : 0u);
+    dev[2 * s + 1] = bc[2 * s + 1];
+  }
+  m->tab.kind = DTK_KIND_DA;
+  m->tab.entry_bytes = 8;
+  m->tab.da_len = (uint32_t)L;
+  m->tab.da_size = size;
+  m->tab.da_base1 = dev[2];
+  m->tab.start = 1;
+  return upload(m, dev.data(), dev.size() * 4);
+}
+
+extern "C" int dtk_model_load_mem(const void *gz_bytes, size_t n, dtk_model **out) {
+  if (!gz_bytes || !out) return DTK_E_ARG;
+  *out = nullptr;
+  if (dtk_device_count() <= 0) return DTK_E_NO_DEVICE;
+  std::vector<uint8_t> raw;
+  int rc = gunzip((const uint8_t *)gz_bytes, n, raw);
+  if (rc != DTK_OK) return rc;
+  if (raw.size() < 5) return DTK_E_FORMAT;
+  dtk_model *m = new dtk_model();
+  if (memcmp(raw.data(), "MATOK", 5) == 0) rc = build_matrix(m, raw);      // fomafile.go:476
+  else if (memcmp(raw.data(), "DATOK", 5) == 0) rc = build_datok(m, raw);  // fomafile.go:478
+  else rc = DTK_E_FORMAT;                                                  // fomafile.go:482
+  if (rc != DTK_OK) { dtk_model_free(m); return rc; }
+  *out = m;
+  return DTK_OK;
+}
+
+extern "C" int dtk_model_load(const char *path, dtk_model **out) {
+  if (!path || !out) return DTK_E_ARG;
+  *out = nullptr;
+  FILE *f = fopen(path, "rb");
+  if (!f) return DTK_E_IO;
+  std::vector<uint8_t> gz;
+  uint8_t buf[1 << 16];
+  size_t k;
+  while ((k = fread(buf, 1, sizeof buf, f)) > 0) gz.insert(gz.end(), buf, buf + k);
+  const bool bad = ferror(f) != 0;
+  fclose(f);
+  if (bad) return DTK_E_IO;
+  return dtk_model_load_mem(gz.data(), gz.size(), out);
+}
+
+extern "C" void dtk_model_free(dtk_model *m) {
+  if (!m) return;
+  if (m->d_tab) (void)hipFree(m->d_tab);
+  if (m->d_ascii) (void)hipFree(m->d_ascii);
+  if (m->d_runes) (void)hipFree(m->d_runes);
+  if (m->d_syms) (void)hipFree(m->d_syms);
+  delete m;
+}
+
+extern "C" const char *dtk_model_type(const dtk_model *m) {
+  return m->kind == DTK_KIND_MATRIX ? "MATOK" : "DATOK";
+}
+
+extern "C" int dtk_model_get_info(const dtk_model *m, dtk_model_info *o) {
+  if (!m || !o) return DTK_E_ARG;
+  o->kind = m->kind; o->epsilon = m->epsilon; o->unknown = m->unknown; o->identity = m->identity;
+  o->final_state = m->final_state; o->sigma_count = m->sigma_count; o->state_count = m->state_count;
+  o->array_len = m->array_len; o->n_eps_states = m->n_eps_states; o->max_eps_chain = m->max_eps_chain;
+  o->entry_bytes = m->tab.entry_bytes; o->device_bytes = m->device_bytes; o->unknown_used = m->unknown_used;
+  return DTK_OK;
+}
+
+// -------------------------------------------------------------------- batch
+
+struct dtk_batch {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  uint64_t max_bytes = 0;
+  uint32_t max_docs = 0;
+  // inputs
+  uint8_t *d_text_own = nullptr;
+  uint64_t *d_off_own = nullptr;
+  const uint8_t *d_text = nullptr;
+  const uint64_t *d_off = nullptr;
+  uint32_t n_docs = 0;
+  uint64_t total = 0;
+  // intermediates
+  uint16_t *d_sym = nullptr;
+  uint8_t *d_events = nullptr;
+  uint32_t *d_status = nullptr;
+  uint64_t *d_tok_off = nullptr, *d_sent_off = nullptr, *d_text_off = nullptr;
+  uint64_t *d_totals = nullptr;  // [0..3] scan totals, [4] walk steps
+  uint64_t *h_totals = nullptr;  // pinned
+  // outputs (grown on demand, never inside a run unless a re-launch is needed)
+  uint64_t tok_cap = 0, sent_cap = 0, text_cap = 0;
+  int32_t *d_rstart = nullptr, *d_rend = nullptr, *d_sent = nullptr;
+  uint32_t *d_bstart = nullptr, *d_bend = nullptr, *d_ttok = nullptr, *d_tsent = nullptr;
+  // optional stage timing
+  bool profiling = false;
+  hipEvent_t ev[7] = {};
+  // last run
+  bool ran = false, totals_valid = false;
+  DtkCompactArgs last_args{};
+  dtk_totals totals{};
+  // host mirrors for dtk_batch_result_host
+  std::vector<uint64_t> h_tok_off, h_sent_off, h_text_off;
+  std::vector<int32_t> h_rstart, h_rend, h_sent;
+  std::vector<uint32_t> h_bstart, h_bend, h_ttok, h_tsent, h_status;
+  std::vector<uint8_t> h_events;
+};
+
+static int alloc_outputs(dtk_batch *b, uint64_t tok, uint64_t sent, uint64_t text) {
+  auto grow = [&](auto *&p, uint64_t n) -> int {
+    if (p) HIP_TRY(hipFree(p));
+    p = nullptr;
+    HIP_TRY(hipMalloc((void **)&p, std::max<uint64_t>(n, 4) * 4));
+    return DTK_OK;
+  };
+  int rc;
+  if (tok > b->tok_cap) {
+    if ((rc = grow(b->d_rstart, tok))) return rc;
+    if ((rc = grow(b->d_rend, tok))) return rc;
+    if ((rc = grow(b->d_bstart, tok))) return rc;
+    if ((rc = grow(b->d_bend, tok))) return rc;
+    b->tok_cap = tok;
+  }
+  if (sent > b->sent_cap) {
+    if ((rc = grow(b->d_sent, sent))) return rc;
+    b->sent_cap = sent;
+  }
+  if (text > b->text_cap) {
+    if ((rc = grow(b->d_ttok, text))) return rc;
+    if ((rc = grow(b->d_tsent, text))) return rc;
+    b->text_cap = text;
+  }
+  return DTK_OK;
+}
+
+extern "C" int dtk_batch_create(uint64_t max_bytes, uint32_t max_docs, dtk_batch **out) {
+  if (!out || max_docs == 0) return DTK_E_ARG;
+  *out = nullptr;
+  if (dtk_device_count() <= 0) return DTK_E_NO_DEVICE;
+  dtk_batch *b = new dtk_batch();
+  b->max_bytes = max_bytes;
+  b->max_docs = max_docs;
+  auto fail = [&](int rc) { dtk_batch_free(b); return rc; };
+#define B_TRY(call)                                                  \
+  do {                                                               \
+    hipError_t e_ = (call);                                          \
+    if (e_ != hipSuccess) return fail(hip_fail(e_, #call));          \
+  } while (0)
+  B_TRY(hipGetDevice(&b->device));
+  B_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+  const uint64_t pad = 256;
+  B_TRY(hipMalloc((void **)&b->d_text_own, max_bytes + pad));
+  B_TRY(hipMalloc((void **)&b->d_off_own, ((uint64_t)max_docs + 1) * 8));
+  B_TRY(hipMalloc((void **)&b->d_sym, (max_bytes + pad) * 2));
+  B_TRY(hipMalloc((void **)&b->d_events, max_bytes + max_docs + pad));
+  B_TRY(hipMalloc((void **)&b->d_status, (uint64_t)max_docs * 4));
+  B_TRY(hipMalloc((void **)&b->d_tok_off, ((uint64_t)max_docs + 1) * 8));
+  B_TRY(hipMalloc((void **)&b->d_sent_off, ((uint64_t)max_docs + 1) * 8));
+  B_TRY(hipMalloc((void **)&b->d_text_off, ((uint64_t)max_docs + 1) * 8));
+  B_TRY(hipMalloc((void **)&b->d_totals, 8 * 8));
+  B_TRY(hipHostMalloc((void **)&b->h_totals, 8 * 8, hipHostMallocDefault));
+#undef B_TRY
+  // typical German: 0.18 tokens and 0.06 sentence ints per byte; grown on demand
+  int rc = alloc_outputs(b, max_bytes / 3 + max_docs + 16, max_bytes / 8 + 2ull * max_docs + 16,
+                         max_bytes / 64 + 2ull * max_docs + 16);
+  if (rc != DTK_OK) return fail(rc);
+  *out = b;
+  return DTK_OK;
+}
+
+extern "C" void dtk_batch_free(dtk_batch *b) {
+  if (!b) return;
+  if (b->stream) (void)hipStreamSynchronize(b->stream);
+  void *ptrs[] = {b->d_text_own, b->d_off_own, b->d_sym, b->d_events, b->d_status, b->d_tok_off,
+                  b->d_sent_off, b->d_text_off, b->d_totals, b->d_rstart, b->d_rend, b->d_sent,
+                  b->d_bstart, b->d_bend, b->d_ttok, b->d_tsent};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+  if (b->h_totals) (void)hipHostFree(b->h_totals);
+  for (hipEvent_t e : b->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (b->stream) (void)hipStreamDestroy(b->stream);
+  delete b;
+}
+
+extern "C" void *dtk_batch_stream(dtk_batch *b) { return b ? (void *)b->stream : nullptr; }
+
+extern "C" int dtk_batch_set_input(dtk_batch *b, const uint8_t *text, const uint64_t *doc_off, uint32_t n_docs) {
+  if (!b || !doc_off || n_docs == 0) return DTK_E_ARG;
+  if (n_docs > b->max_docs) return DTK_E_CAPACITY;
+  if (doc_off[0] != 0) return DTK_E_ARG;
+  for (uint32_t d = 0; d < n_docs; d++) {
+    if (doc_off[d + 1] < doc_off[d]) return DTK_E_ARG;
+    if (doc_off[d + 1] - doc_off[d] >= 0x7FFFFFF0ull) return DTK_E_ARG;  // 31-bit cursor positions
+  }
+  const uint64_t total = doc_off[n_docs];
+  if (total > b->max_bytes) return DTK_E_CAPACITY;
+  if (total && !text) return DTK_E_ARG;
+  HIP_TRY(hipStreamSynchronize(b->stream));  // previous run may still read the buffers
+  if (total) HIP_TRY(hipMemcpyAsync(b->d_text_own, text, total, hipMemcpyHostToDevice, b->stream));
+  HIP_TRY(hipMemcpyAsync(b->d_off_own, doc_off, ((uint64_t)n_docs + 1) * 8, hipMemcpyHostToDevice, b->stream));
+  b->d_text = b->d_text_own;
+  b->d_off = b->d_off_own;
+  b->n_docs = n_docs;
+  b->total = total;
+  b->ran = false;
+  return DTK_OK;
+}
+
+extern "C" int dtk_batch_set_input_device(dtk_batch *b, const void *d_text, const void *d_doc_off,
+                                          uint32_t n_docs, uint64_t total_bytes) {
+  if (!b || !d_doc_off || n_docs == 0 || (total_bytes && !d_text)) return DTK_E_ARG;
+  if (n_docs > b->max_docs || total_bytes > b->max_bytes) return DTK_E_CAPACITY;
+  b->d_text = (const uint8_t *)d_text;
+  b->d_off = (const uint64_t *)d_doc_off;
+  b->n_docs = n_docs;
+  b->total = total_bytes;
+  b->ran = false;
+  return DTK_OK;
+}
+
+static int launch_compact2(dtk_batch *b) {
+  DtkCompactArgs a = b->last_args;
+  a.tok_rstart = b->d_rstart; a.tok_rend = b->d_rend;
+  a.tok_bstart = b->d_bstart; a.tok_bend = b->d_bend;
+  a.sent = b->d_sent; a.text_tok_end = b->d_ttok; a.text_sent_end = b->d_tsent;
+  a.tok_cap = b->tok_cap; a.sent_cap = b->sent_cap; a.text_cap = b->text_cap;
+  b->last_args = a;
+  if (dtk_launch_compact(&a, 2, b->stream)) return hip_fail(hipGetLastError(), "compact pass 2");
+  return DTK_OK;
+}
+
+extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
+  if (!m || !b) return DTK_E_ARG;
+  if (b->n_docs == 0 || !b->d_off) return DTK_E_STATE;
+  if (m->device != b->device) return DTK_E_ARG;
+  hipStream_t s = b->stream;
+  const bool prof = b->profiling;
+#define STAGE(i) do { if (prof) HIP_TRY(hipEventRecord(b->ev[i], s)); } while (0)
+  STAGE(0);
+  HIP_TRY(hipMemsetAsync(b->d_events, 0, b->total + b->n_docs, s));
+  HIP_TRY(hipMemsetAsync(b->d_totals, 0, 8 * 8, s));
+  STAGE(1);
+  if (dtk_launch_symbolize(b->d_text, b->d_off, b->n_docs, b->total, &m->sig, b->d_sym, s))
+    return hip_fail(hipGetLastError(), "symbolize");
+  STAGE(2);
+  DtkWalkArgs w{};
+  w.sym = b->d_sym; w.doc_off = b->d_off; w.n_docs = b->n_docs;
+  w.events = b->d_events; w.status = b->d_status;
+  w.steps = (unsigned long long *)(b->d_totals + 4);
+  w.step_factor = 2048;  // look-ahead is bounded by the 1024-rune window (matrix.go:365)
+  if (dtk_launch_walk(&m->tab, &w, s)) return hip_fail(hipGetLastError(), "walk");
+  STAGE(3);
+  DtkCompactArgs c{};
+  c.text = b->d_text; c.sym = b->d_sym; c.doc_off = b->d_off; c.n_docs = b->n_docs;
+  c.events = b->d_events; c.status = b->d_status;
+  c.flags = flags & DTK_NEWLINE_AFTER_EOT; c.kind = m->kind;
+  c.tok_off = b->d_tok_off; c.sent_off = b->d_sent_off; c.text_off = b->d_text_off;
+  c.totals = b->d_totals;
+  if (dtk_launch_compact(&c, 1, s)) return hip_fail(hipGetLastError(), "compact pass 1");
+  STAGE(4);
+  if (dtk_launch_scan3(b->d_tok_off, b->d_sent_off, b->d_text_off, b->n_docs, b->d_totals, b->d_status, s))
+    return hip_fail(hipGetLastError(), "scan");
+  STAGE(5);
+  b->last_args = c;
+  int rc = launch_compact2(b);
+  if (rc != DTK_OK) return rc;
+  STAGE(6);
+#undef STAGE
+  HIP_TRY(hipMemcpyAsync(b->h_totals, b->d_totals, 8 * 8, hipMemcpyDeviceToHost, s));
+  b->ran = true;
+  b->totals_valid = false;
+  return DTK_OK;
+}
+
+extern "C" int dtk_batch_set_profiling(dtk_batch *b, int enable) {
+  if (!b) return DTK_E_ARG;
+  if (enable && !b->ev[0])
+    for (auto &e : b->ev) HIP_TRY(hipEventCreate(&e));
+  b->profiling = enable != 0;
+  return DTK_OK;
+}
+
+extern "C" int dtk_batch_stage_ms(dtk_batch *b, float ms[6]) {
+  if (!b || !ms) return DTK_E_ARG;
+  if (!b->ran || !b->profiling) return DTK_E_STATE;
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  for (int i = 0; i < 6; i++) HIP_TRY(hipEventElapsedTime(&ms[i], b->ev[i], b->ev[i + 1]));
+  return DTK_OK;
+}
+
+extern "C" int dtk_batch_sync(dtk_batch *b) {
+  if (!b) return DTK_E_ARG;
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  return DTK_OK;
+}
+
+// Reads the totals; if pass 2 found its arrays too small, grows them and runs
+// pass 2 again (the only allocation that can follow a run).
+static int finish(dtk_batch *b) {
+  if (!b->ran) return DTK_E_STATE;
+  if (b->totals_valid) return DTK_OK;
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  const uint64_t nt = b->h_totals[0], ns = b->h_totals[1], nx = b->h_totals[2];
+  if (nt > b->tok_cap || ns > b->sent_cap || nx > b->text_cap) {
+    int rc = alloc_outputs(b, nt + nt / 8 + 16, ns + ns / 8 + 16, nx + nx / 8 + 16);
+    if (rc != DTK_OK) return rc;
+    rc = launch_compact2(b);
+    if (rc != DTK_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(b->stream));
+  }
+  b->totals.n_docs = b->n_docs;
+  b->totals.n_bytes = b->total;
+  b->totals.n_tokens = nt;
+  b->totals.n_sent = ns;
+  b->totals.n_texts = nx;
+  b->totals.n_flagged = b->h_totals[3];
+  b->totals.walk_steps = b->h_totals[4];
+  b->totals_valid = true;
+  return DTK_OK;
+}
+
+extern "C" int dtk_batch_totals(dtk_batch *b, dtk_totals *out) {
+  if (!b || !out) return DTK_E_ARG;
+  int rc = finish(b);
+  if (rc != DTK_OK) return rc;
+  *out = b->totals;
+  return DTK_OK;
+}
+
+extern "C" int dtk_batch_result_device(dtk_batch *b, dtk_result_view *o) {
+  if (!b || !o) return DTK_E_ARG;
+  int rc = finish(b);
+  if (rc != DTK_OK) return rc;
+  o->tok_off = b->d_tok_off; o->sent_off = b->d_sent_off; o->text_off = b->d_text_off;
+  o->tok_rstart = b->d_rstart; o->tok_rend = b->d_rend;
+  o->tok_bstart = b->d_bstart; o->tok_bend = b->d_bend;
+  o->sent = b->d_sent; o->text_tok_end = b->d_ttok; o->text_sent_end = b->d_tsent;
+  o->status = b->d_status; o->events = b->d_events;
+  return DTK_OK;
+}
+
+extern "C" int dtk_batch_result_host(dtk_batch *b, dtk_result_view *o) {
+  if (!b || !o) return DTK_E_ARG;
+  int rc = finish(b);
+  if (rc != DTK_OK) return rc;
+  const uint64_t nd = b->n_docs, nt = b->totals.n_tokens, ns = b->totals.n_sent, nx = b->totals.n_texts;
+  auto get = [&](auto &vec, const void *src, uint64_t n) -> int {
+    vec.resize(std::max<uint64_t>(n, 1));
+    if (n) HIP_TRY(hipMemcpy(vec.data(), src, n * sizeof(vec[0]), hipMemcpyDeviceToHost));
+    return DTK_OK;
+  };
+  if ((rc = get(b->h_tok_off, b->d_tok_off, nd + 1))) return rc;
+  if ((rc = get(b->h_sent_off, b->d_sent_off, nd + 1))) return rc;
+  if ((rc = get(b->h_text_off, b->d_text_off, nd + 1))) return rc;
+  if ((rc = get(b->h_rstart, b->d_rstart, nt))) return rc;
+  if ((rc = get(b->h_rend, b->d_rend, nt))) return rc;
+  if ((rc = get(b->h_bstart, b->d_bstart, nt))) return rc;
+  if ((rc = get(b->h_bend, b->d_bend, nt))) return rc;
+  if ((rc = get(b->h_sent, b->d_sent, ns))) return rc;
+  if ((rc = get(b->h_ttok, b->d_ttok, nx))) return rc;
+  if ((rc = get(b->h_tsent, b->d_tsent, nx))) return rc;
+  if ((rc = get(b->h_status, b->d_status, nd))) return rc;
+  if ((rc = get(b->h_events, b->d_events, b->total + nd))) return rc;
+  o->tok_off = b->h_tok_off.data(); o->sent_off = b->h_sent_off.data(); o->text_off = b->h_text_off.data();
+  o->tok_rstart = b->h_rstart.data(); o->tok_rend = b->h_rend.data();
+  o->tok_bstart = b->h_bstart.data(); o->tok_bend = b->h_bend.data();
+  o->sent = b->h_sent.data(); o->text_tok_end = b->h_ttok.data(); o->text_sent_end = b->h_tsent.data();
+  o->status = b->h_status.data(); o->events = b->h_events.data();
+  return DTK_OK;
+}
+
+extern "C" void dtk_free(void *p) { free(p); }

@@ -1,0 +1,120 @@
+// dtk_internal.h -- structures shared by the host side and the gfx950 kernels.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#define DTK_FIRSTBIT 0x80000000u   // datok.go:43
+#define DTK_SECONDBIT 0x40000000u  // datok.go:44
+#define DTK_RESTBIT 0x3fffffffu    // datok.go:45
+#define DTK_EOT 4u                 // matrix.go:13
+#define DTK_WINDOW 1024u           // matrix.go:365
+
+// ---- symbol stream entry (uint16 per input byte), written by the symbolise kernel
+//   [10:0]  sigma index a           (sigmaASCII[c] / sigma[c] / identity, matrix.go:421-435)
+//   [12:11] UTF-8 width - 1         (Go DecodeRune width)
+//   [14:13] class: 0 rune<256, 1 rune==EOT, 2 rune>=256 in sigma (ok=true), 3 not in sigma (ok=false)
+//   [15]    this byte starts a rune
+#define DTK_SYM_MASK 0x7FFu
+#define DTK_SYM_MAX 2047u
+#define DTK_SYM_W_SHIFT 11
+#define DTK_SYM_CLS_SHIFT 13
+#define DTK_SYM_START 0x8000u
+
+// ---- event byte (one per byte position 0..len of every document); bit order is
+// the order in which the reference fires the calls at one cursor position: the
+// cursor only reaches the byte behind an EOT by consuming it, which fires
+// SentenceEnd/TextEnd at once (matrix.go:593-600), so those precede a token that
+// ends there (possible for the double array only, which keeps its window).
+#define EV_S_EOT 0x01u
+#define EV_E_EOT 0x02u
+#define EV_TOK_END 0x04u
+#define EV_S_EPS 0x08u
+#define EV_S_EPS2 0x10u
+#define EV_S_EOF 0x20u
+#define EV_E_EOF 0x40u
+#define EV_TOK_START 0x80u
+#define EV_SMASK (EV_S_EOT | EV_S_EPS | EV_S_EPS2 | EV_S_EOF)
+#define EV_EMASK (EV_E_EOT | EV_E_EOF)
+
+// per-document status (mirrors DTK_ST_* of datok_gpu.h)
+#define ST_WINDOW_OVERFLOW 1u
+#define ST_EMPTY_TEXT 2u
+#define ST_BAD_MODEL 4u
+#define ST_IRREGULAR 8u
+#define ST_STEP_LIMIT 16u
+
+struct DtkSigmaDev {
+  const uint16_t *ascii;  // [256] symbol per rune < 256 (identity pre-filled, matrix.go:289-293)
+  const uint32_t *runes;  // sorted runes of the sigma map (matrix.go:301)
+  const uint16_t *syms;   // their symbols
+  uint32_t n_runes;
+  uint32_t identity;
+};
+
+enum { DTK_KIND_MATRIX = 0, DTK_KIND_DA = 1 };
+
+// Device table handed to the walk kernels.
+struct DtkTableDev {
+  int kind;
+  // matrix: state-major rows, cell (t, a) at tab[t*stride + a]; column 0 is all
+  // zero (the a == 0 guard of matrix.go:459).  cell = target | nontoken flag in
+  // the top bit.  States are renumbered so that exactly the states 1..n_eps
+  // have an epsilon arc (the probe of matrix.go:442 becomes a compare).
+  // double array: {base, check} pairs as in the file (datok.go:56-59); bit 30 of
+  // base (unused upstream, masked by getBase, datok.go:271-273) caches "this
+  // index has an epsilon arc" so the probe of datok.go:876 needs no extra load.
+  const void *tab;
+  uint32_t entry_bytes;  // 2 or 4 (matrix), 8 (double array)
+  uint32_t stride;       // matrix: cells per row
+  uint32_t n_states;     // matrix: highest state id
+  uint32_t n_eps;        // matrix: states 1..n_eps have an epsilon arc
+  uint32_t start;        // image of the reference's state 1
+  uint32_t da_len;       // double array: pairs
+  uint32_t da_size;      // array[1].check & RESTBIT (datok.go:333-335)
+  uint32_t da_base1;     // device base word of index 1
+  uint32_t epsilon, unknown, identity;
+};
+
+struct DtkWalkArgs {
+  const uint16_t *sym;      // symbol stream, one entry per input byte
+  const uint64_t *doc_off;  // n_docs + 1
+  uint32_t n_docs;
+  uint8_t *events;          // zero-filled; index doc_off[d] + d + p
+  uint32_t *status;         // per document, OR-ed
+  unsigned long long *steps;  // global lookup counter
+  uint32_t step_factor;     // cap = step_factor * (len + 2) lookups per document
+};
+
+struct DtkCompactArgs {
+  const uint8_t *text;
+  const uint16_t *sym;
+  const uint64_t *doc_off;
+  uint32_t n_docs;
+  const uint8_t *events;
+  uint32_t *status;
+  uint32_t flags;           // DTK_NEWLINE_AFTER_EOT
+  int kind;                 // matrix / double array (EOT rewind rule differs)
+  // pass 1 output: per document counts (tokens, sentence ints, texts)
+  uint64_t *tok_off, *sent_off, *text_off;  // n_docs+1; counts in [d], scanned in place
+  // pass 2 output
+  int32_t *tok_rstart, *tok_rend;
+  uint32_t *tok_bstart, *tok_bend;
+  int32_t *sent;
+  uint32_t *text_tok_end, *text_sent_end;
+  const uint64_t *totals;   // [0..2] tokens, sentence ints, texts (written by the scan)
+  uint64_t tok_cap, sent_cap, text_cap;
+};
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+// launchers (dtk_kernels.hip); stream is a hipStream_t
+int dtk_launch_symbolize(const uint8_t *text, const uint64_t *doc_off, uint32_t n_docs,
+                         uint64_t total, const struct DtkSigmaDev *sig, uint16_t *sym, void *stream);
+int dtk_launch_walk(const struct DtkTableDev *tab, const struct DtkWalkArgs *args, void *stream);
+int dtk_launch_compact(const struct DtkCompactArgs *args, int pass, void *stream);
+int dtk_launch_scan3(uint64_t *a, uint64_t *b, uint64_t *c, uint32_t n_docs, uint64_t *totals,
+                     const uint32_t *status, void *stream);
+#ifdef __cplusplus
+}
+#endif

@@ -1,0 +1,732 @@
+// dtk_kernels.hip -- gfx950 (MI355X, wave64) kernels of the batch tokenizer.
+//
+// Pipeline per batch (all on one HIP stream, no host round trip):
+//   1. symbolise : bytes -> uint16 symbol stream (UTF-8 decode with Go's
+//                  DecodeRune rules + sigma lookup), fully parallel, HBM bound.
+//   2. walk      : the FSA transition walk of matrix.go:348-698 /
+//                  datok.go:781-1135, one document per lane, writing one event
+//                  byte per cursor position (no output allocation problem).
+//   3. compact   : wave-per-document ballot / popcount / prefix-sum pass that
+//                  turns event bytes into the offset arrays NewTokenWriter
+//                  (token_writer.go:36-175) would have collected.  Pass 1
+//                  counts, a scan sizes the CSR rows, pass 2 writes.
+//
+// Integer table lookups only: no MFMA.  The walk is a per-lane dependent-load
+// chain (latency bound); 1 and 3 are streaming passes.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dtk_internal.h"
+
+#define WAVE 64
+
+// ------------------------------------------------------------------ helpers
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & (WAVE - 1); }
+__device__ __forceinline__ unsigned long long lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+__device__ __forceinline__ int highest(unsigned long long m) { return 63 - __clzll((long long)m); }
+__device__ __forceinline__ uint32_t popc(unsigned long long m) { return (uint32_t)__popcll(m); }
+
+// Go unicode/utf8.DecodeRune on up to 4 bytes (b0..b3), `avail` of which exist
+// in the document (the decoder behind bufio.ReadRune, matrix.go:392).
+__device__ __forceinline__ uint32_t go_decode(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3,
+                                              uint32_t avail, uint32_t &rune) {
+  rune = 0xFFFDu;
+  if (b0 < 0x80u) { rune = b0; return 1; }
+  if (b0 < 0xC2u || b0 > 0xF4u) return 1;
+  if (b0 < 0xE0u) {
+    if (avail < 2 || (b1 & 0xC0u) != 0x80u) return 1;
+    rune = ((b0 & 0x1Fu) << 6) | (b1 & 0x3Fu);
+    return 2;
+  }
+  if (b0 < 0xF0u) {
+    uint32_t lo = b0 == 0xE0u ? 0xA0u : 0x80u, hi = b0 == 0xEDu ? 0x9Fu : 0xBFu;
+    if (avail < 3 || b1 < lo || b1 > hi || (b2 & 0xC0u) != 0x80u) return 1;
+    rune = ((b0 & 0x0Fu) << 12) | ((b1 & 0x3Fu) << 6) | (b2 & 0x3Fu);
+    return 3;
+  }
+  uint32_t lo = b0 == 0xF0u ? 0x90u : 0x80u, hi = b0 == 0xF4u ? 0x8Fu : 0xBFu;
+  if (avail < 4 || b1 < lo || b1 > hi || (b2 & 0xC0u) != 0x80u || (b3 & 0xC0u) != 0x80u) return 1;
+  rune = ((b0 & 0x07u) << 18) | ((b1 & 0x3Fu) << 12) | ((b2 & 0x3Fu) << 6) | (b3 & 0x3Fu);
+  return 4;
+}
+
+// ---------------------------------------------------------------- symbolise
+//
+// One thread per 16 input bytes: one 16-byte load plus the 4 bytes either side
+// (3 bytes of look-back decide whether a continuation byte is covered by an
+// earlier valid sequence, 3 bytes of look-ahead complete a sequence), two
+// 16-byte stores of symbol entries.  Documents never share a rune: look-back
+// and look-ahead stop at the document boundary (reader EOF).
+
+#define SYM_PER_THREAD 16
+
+__global__ __launch_bounds__(256) void k_symbolize(const uint8_t *__restrict__ text,
+                                                   const uint64_t *__restrict__ doc_off,
+                                                   uint32_t n_docs, uint64_t total, DtkSigmaDev sig,
+                                                   uint16_t *__restrict__ sym) {
+  const uint64_t g0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * SYM_PER_THREAD;
+  if (g0 >= total) return;
+
+  // window of 24 bytes: w[k] = text[g0 - 4 + k]
+  uint32_t wq[6];
+  const bool aligned = (((uintptr_t)text) & 15u) == 0;
+  if (aligned && g0 + 16 <= total) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(text + g0);
+    wq[1] = v.x; wq[2] = v.y; wq[3] = v.z; wq[4] = v.w;
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      uint32_t x = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        uint64_t g = g0 + q * 4 + k;
+        if (g < total) x |= (uint32_t)text[g] << (8 * k);
+      }
+      wq[1 + q] = x;
+    }
+  }
+  {
+    uint32_t x = 0;
+    if (g0 >= 4) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) x |= (uint32_t)text[g0 - 4 + k] << (8 * k);
+    }
+    wq[0] = x;
+    x = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      uint64_t g = g0 + 16 + k;
+      if (g < total) x |= (uint32_t)text[g] << (8 * k);
+    }
+    wq[5] = x;
+  }
+#define WB(k) ((wq[(k) >> 2] >> (8 * ((k)&3))) & 0xFFu)
+
+  // document containing g0: largest d with doc_off[d] <= g0
+  uint32_t lo = 0, hi = n_docs;  // invariant: doc_off[lo] <= g0, doc_off[hi] > g0
+  while (hi - lo > 1) {
+    uint32_t mid = lo + ((hi - lo) >> 1);
+    if (doc_off[mid] <= g0) lo = mid; else hi = mid;
+  }
+  uint32_t d = lo;
+  uint64_t dstart = doc_off[d], dend = doc_off[d + 1];
+
+  uint32_t outw[8];
+#pragma unroll
+  for (int j = 0; j < SYM_PER_THREAD; j++) {
+    const uint64_t g = g0 + j;
+    uint32_t entry = 0;
+    if (g < total) {
+      while (g >= dend) { d++; dstart = dend; dend = doc_off[d + 1]; }
+      const uint64_t left = dend - g;
+      const uint32_t avail = left > 4 ? 4u : (uint32_t)left;
+      uint32_t rune;
+      const uint32_t b0 = WB(4 + j);
+      const uint32_t width = go_decode(b0, WB(5 + j), WB(6 + j), WB(7 + j), avail, rune);
+      // does this byte start a rune?  a non-continuation byte always does; a
+      // continuation byte does unless the nearest non-continuation byte within
+      // the previous 3 (same document) begins a valid sequence that covers it.
+      uint32_t start = 1;
+      if ((b0 & 0xC0u) == 0x80u) {
+        const uint64_t back = g - dstart;
+#pragma unroll
+        for (int k = 1; k <= 3; k++) {
+          if (start == 1 && (uint64_t)k <= back) {
+            const uint32_t l0 = WB(4 + j - k);
+            if ((l0 & 0xC0u) != 0x80u) {
+              uint32_t r2;
+              const uint64_t left2 = dend - (g - k);
+              const uint32_t w2 = go_decode(l0, WB(5 + j - k), WB(6 + j - k), WB(7 + j - k),
+                                            left2 > 4 ? 4u : (uint32_t)left2, r2);
+              start = (w2 > (uint32_t)k) ? 0u : 2u;  // 2: decided "is a start", stop looking
+            }
+          }
+        }
+        start = start ? 1u : 0u;
+      }
+      uint32_t a, cls;
+      if (rune < 256u) {  // matrix.go:421-426
+        a = sig.ascii[rune];
+        cls = rune == DTK_EOT ? 1u : 0u;
+      } else {  // matrix.go:427-435: a, ok = sigma[char]; !ok -> identity
+        int l = 0, h = (int)sig.n_runes - 1;
+        a = sig.identity;
+        cls = 3u;
+        while (l <= h) {
+          int m = (l + h) >> 1;
+          uint32_t r = sig.runes[m];
+          if (r == rune) { a = sig.syms[m]; cls = 2u; break; }
+          if (r < rune) l = m + 1; else h = m - 1;
+        }
+      }
+      entry = (a & DTK_SYM_MASK) | ((width - 1) << DTK_SYM_W_SHIFT) | (cls << DTK_SYM_CLS_SHIFT) |
+              (start ? DTK_SYM_START : 0u);
+    }
+    if (j & 1) outw[j >> 1] |= entry << 16; else outw[j >> 1] = entry;
+  }
+#undef WB
+  if (g0 + 16 <= total && ((((uintptr_t)sym) & 15u) == 0)) {
+    uint4 *o = reinterpret_cast<uint4 *>(sym + g0);
+    o[0] = make_uint4(outw[0], outw[1], outw[2], outw[3]);
+    o[1] = make_uint4(outw[4], outw[5], outw[6], outw[7]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < SYM_PER_THREAD; j++)
+      if (g0 + j < total) sym[g0 + j] = (uint16_t)(outw[j >> 1] >> (16 * (j & 1)));
+  }
+}
+
+// --------------------------------------------------------------------- walk
+//
+// Transition policies.  A "state" is (t, aux): aux is unused for the matrix and
+// holds the device base word of t for the double array.
+
+template <typename CELL>
+struct MatrixTrans {
+  const CELL *tab;
+  uint32_t stride, n_eps, start;
+  static constexpr CELL FLAG = (CELL)((CELL)1 << (sizeof(CELL) * 8 - 1));
+  __device__ __forceinline__ uint32_t start_state() const { return start; }
+  __device__ __forceinline__ uint32_t start_aux() const { return 0; }
+  // matrix.go:442 `array[(epsilon-1)*stateCount+t0] != 0` after renumbering
+  __device__ __forceinline__ bool has_eps(uint32_t t, uint32_t) const { return t <= n_eps; }
+  // matrix.go:459-464; column 0 is zero so a == 0 fails without a branch
+  __device__ __forceinline__ bool step(uint32_t t0, uint32_t, uint32_t a, uint32_t &t,
+                                       uint32_t &aux, bool &nontoken, uint32_t &st) const {
+    const CELL x = tab[(size_t)t0 * stride + a];
+    t = (uint32_t)(x & (CELL)~FLAG);  // matrix.go:629 t &= ^FIRSTBIT
+    nontoken = (x & FLAG) != 0;       // matrix.go:584
+    aux = 0;
+    (void)st;
+    return t != 0;  // matrix.go:472
+  }
+};
+
+struct DaTrans {
+  const uint2 *arr;  // .x base (bit31 separate, bit30 has-epsilon cache), .y check
+  uint32_t len, size, base1;
+  __device__ __forceinline__ uint32_t start_state() const { return 1u; }  // datok.go:784
+  __device__ __forceinline__ uint32_t start_aux() const { return base1; }
+  // datok.go:876, precomputed per index at load
+  __device__ __forceinline__ bool has_eps(uint32_t, uint32_t aux) const {
+    return (aux & DTK_SECONDBIT) != 0;
+  }
+  // datok.go:889-901 and :1056-1058
+  __device__ __forceinline__ bool step(uint32_t t0, uint32_t aux0, uint32_t a, uint32_t &t,
+                                       uint32_t &aux, bool &nontoken, uint32_t &st) const {
+    const uint32_t idx = (aux0 & DTK_RESTBIT) + a;
+    if (idx >= len) { st |= ST_BAD_MODEL; return false; }  // Go: index panic
+    const uint2 ta = arr[idx];
+    if (idx > size || (ta.y & DTK_RESTBIT) != t0) return false;
+    nontoken = (ta.y & DTK_FIRSTBIT) != 0;  // datok.go:994 isNonToken
+    if (ta.x & DTK_FIRSTBIT) {              // isSeparate: move to the representative
+      t = ta.x & DTK_RESTBIT;
+      if (t >= len) { st |= ST_BAD_MODEL; return false; }
+      aux = arr[t].x;
+    } else {
+      t = idx;
+      aux = ta.x;
+    }
+    return true;
+  }
+};
+
+// Event bytes are written lane-privately.  Cursor positions of successive
+// events never decrease for the matrix walk, so one pending byte per lane is
+// enough; the double array can revisit a position (no rewind at EOT,
+// datok.go:1019-1030), which takes the read-modify-write path.
+struct EventSink {
+  uint8_t *ev;
+  uint32_t cur_p, cur_f, hiw;  // pending position / byte, highest position stored so far
+  uint32_t st;
+  __device__ __forceinline__ void init(uint8_t *e) { ev = e; cur_p = 0xFFFFFFFFu; cur_f = 0; hiw = 0; st = 0; }
+  __device__ __forceinline__ void flush() {
+    if (cur_p != 0xFFFFFFFFu && cur_f) {
+      ev[cur_p] = (uint8_t)cur_f;
+      if (cur_p > hiw) hiw = cur_p;
+    }
+  }
+  template <bool MONOTONIC>
+  __device__ __forceinline__ void emit(uint32_t p, uint32_t bit) {
+    if (p != cur_p) {
+      flush();
+      cur_f = 0;
+      if (!MONOTONIC) {
+        if (cur_p != 0xFFFFFFFFu && p <= hiw) cur_f = ev[p];
+      }
+      cur_p = p;
+    }
+    if (bit == EV_S_EPS && (cur_f & EV_S_EPS)) {
+      if (cur_f & EV_S_EPS2) st |= ST_IRREGULAR;
+      bit = EV_S_EPS2;
+    } else if ((bit & (EV_E_EOT | EV_S_EOT | EV_TOK_END | EV_TOK_START)) && (cur_f & bit)) {
+      st |= ST_IRREGULAR;
+    }
+    cur_f |= bit;
+  }
+};
+
+template <typename TRANS, bool IS_MATRIX>
+__global__ __launch_bounds__(WAVE) void k_walk(TRANS tr, DtkWalkArgs A, uint32_t epsilon,
+                                               uint32_t unknown, uint32_t identity) {
+  const uint32_t d = blockIdx.x * WAVE + threadIdx.x;
+  uint32_t my_steps = 0;
+  if (d < A.n_docs) {
+    const uint64_t off = A.doc_off[d];
+    const uint32_t len = (uint32_t)(A.doc_off[d + 1] - off);
+    const uint16_t *__restrict__ s = A.sym + off;
+    EventSink sink;
+    sink.init(A.events + off + d);
+
+    // loop state, named after matrix.go:349-381
+    uint32_t a = 0, t0 = 0, aux0 = 0;
+    uint32_t t = tr.start_state();  // matrix.go:351 `t := uint32(1)`
+    uint32_t aux = tr.start_aux();
+    const uint32_t t_start = t, aux_start = aux;
+    bool ok = false;                         // sticky `ok` of matrix.go:352 / datok.go:785
+    uint32_t eps_t = 0, eps_aux = 0, eps_p = 0, eps_r = 0;  // epsilonState / epsilonOffset
+    bool sentence_end = false, text_end = false;
+    uint32_t p = 0;    // byte position of buffer[buffc]
+    uint32_t tp = 0;   // byte position of buffer[bufft]
+    uint32_t hi = 0;   // byte position behind buffer[buffi-1]: read high-water mark
+    uint32_t rc = 0;   // buffc (runes since the last rewind)
+    uint32_t ri = 0;   // buffi
+    uint32_t w = 1;    // width of the rune at p
+    bool eot = false, newchar = true;
+    uint32_t st = 0;
+    unsigned long long cap64 = (unsigned long long)A.step_factor * ((unsigned long long)len + 2ull);
+    const uint32_t cap = cap64 > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)cap64;
+
+    for (;;) {
+      if (newchar) {
+        if (p >= len) {  // p == hi == len: nothing buffered, reader at EOF
+          // reader EOF: the drain of matrix.go:650-668 / datok.go:1085-1103
+          t0 = t; aux0 = aux;
+          a = epsilon;
+          newchar = false;
+          if (tr.has_eps(t0, aux0)) {
+            // goto PARSECHARM with a = epsilon
+          } else if (eps_t != 0) {
+            t0 = eps_t; aux0 = eps_aux;
+            eps_t = 0;
+            p = eps_p; rc = eps_r;
+          } else {
+            break;
+          }
+        } else {
+          const uint32_t e = s[p];
+          a = e & DTK_SYM_MASK;
+          w = ((e >> DTK_SYM_W_SHIFT) & 3u) + 1u;
+          const uint32_t cls = (e >> DTK_SYM_CLS_SHIFT) & 3u;
+          if (p >= hi) {  // a rune not yet in the window (matrix.go:388-408)
+            if (ri >= DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
+            ri++;
+            hi = p + w;
+          }
+          eot = cls == 1u;                 // matrix.go:422
+          if (cls >= 2u) ok = cls == 2u;   // matrix.go:427: only runes >= 256 write `ok`
+          t0 = t; aux0 = aux;              // matrix.go:437
+          if (tr.has_eps(t0, aux0)) {      // matrix.go:442-454
+            eps_t = t0; eps_aux = aux0; eps_p = p; eps_r = rc;
+          }
+        }
+      }
+
+      bool nontoken = false;
+      const bool good = tr.step(t0, aux0, a, t, aux, nontoken, st);
+      if (++my_steps > cap) { st |= ST_STEP_LIMIT; break; }
+
+      if (!good) {
+        if (!ok && a == identity) {  // matrix.go:478-485
+          a = unknown;
+          newchar = false; eot = false;
+        } else if (a != epsilon && eps_t != 0) {  // matrix.go:487-497
+          t0 = eps_t; aux0 = eps_aux;
+          eps_t = 0;
+          p = eps_p; rc = eps_r;
+          a = epsilon;
+          newchar = false; eot = false;
+        } else {  // matrix.go:499-552: drop what is buffered as a token, restart at state 1
+          if (a == epsilon) { st |= ST_BAD_MODEL; break; }  // would hand out stale buffer runes
+          if (p <= tp) { p += w; rc++; }                    // matrix.go:515-516
+          sink.emit<IS_MATRIX>(tp, EV_TOK_START);
+          sink.emit<IS_MATRIX>(p, EV_TOK_END);              // matrix.go:528
+          sentence_end = false; text_end = false;
+          ri -= rc; rc = 0; tp = p;                         // matrix.go:537-543
+          eps_t = 0;
+          t = t_start; aux = aux_start;                     // matrix.go:548
+          newchar = true;
+        }
+        continue;
+      }
+
+      bool rewind = false;
+      if (a == epsilon) {  // matrix.go:563-576
+        if (p > tp) {
+          sink.emit<IS_MATRIX>(tp, EV_TOK_START);
+          sink.emit<IS_MATRIX>(p, EV_TOK_END);
+          rewind = true;
+          sentence_end = false; text_end = false;
+        } else {
+          sentence_end = true;
+          sink.emit<IS_MATRIX>(p, EV_S_EPS);
+        }
+      } else {  // matrix.go:579-591
+        const bool first = p == tp;
+        p += w; rc++;
+        if (first && nontoken) tp = p;
+      }
+      if (eot) {  // matrix.go:593-605 / datok.go:1019-1030
+        eot = false;
+        if (!sentence_end) { sentence_end = true; sink.emit<IS_MATRIX>(p, EV_S_EOT); }
+        text_end = true;
+        sink.emit<IS_MATRIX>(p, EV_E_EOT);
+        if (IS_MATRIX) rewind = true;  // matrix.go:601; the double array keeps its window
+      }
+      if (rewind) {  // matrix.go:608-627
+        ri -= rc; rc = 0; tp = p;
+        eps_t = 0;
+      }
+      newchar = true;
+    }
+
+    if (!(st & (ST_STEP_LIMIT | ST_BAD_MODEL))) {
+      if (p > tp) {  // matrix.go:671-678
+        sink.emit<IS_MATRIX>(tp, EV_TOK_START);
+        sink.emit<IS_MATRIX>(p, EV_TOK_END);
+        sentence_end = false; text_end = false;
+      }
+      if (!sentence_end) sink.emit<IS_MATRIX>(p, EV_S_EOF);  // matrix.go:683-684
+      if (!text_end) sink.emit<IS_MATRIX>(p, EV_E_EOF);      // matrix.go:690-691
+    }
+    sink.flush();
+    A.status[d] = st | sink.st;
+  }
+  // one atomic per wave for the lookup counter
+  unsigned long long tot = my_steps;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) tot += __shfl_down(tot, o);
+  if (lane_id() == 0 && tot) atomicAdd(A.steps, tot);
+}
+
+// ------------------------------------------------------------------ compact
+//
+// One wave per document.  Each iteration looks at 64 consecutive cursor
+// positions: lane i holds the event byte of position base+i, whether a rune
+// starts there, and the input byte.  Everything NewTokenWriter tracks
+// (token_writer.go:38-42: posC, pos, sentB, sent) is recovered with ballots,
+// popcounts of the lanes below, and a handful of shuffles; wave-uniform carries
+// link the tiles.  Order of the calls at one position = bit order of the byte.
+
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total) {
+  uint32_t x = v;
+#pragma unroll
+  for (int o = 1; o < WAVE; o <<= 1) {
+    uint32_t y = __shfl_up(x, o);
+    if ((int)lane_id() >= o) x += y;
+  }
+  total = __shfl(x, WAVE - 1);
+  return x - v;
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
+  const uint32_t d = blockIdx.x;
+  if (d >= A.n_docs) return;
+  const uint64_t off = A.doc_off[d];
+  const uint32_t len = (uint32_t)(A.doc_off[d + 1] - off);
+  const uint8_t *__restrict__ ev = A.events + off + d;
+  const uint16_t *__restrict__ sym = A.sym + off;
+  const uint8_t *__restrict__ txt = A.text + off;
+  const bool nl_rule = (A.flags & 16u) != 0;  // NEWLINE_AFTER_EOT
+  const bool is_matrix = A.kind == DTK_KIND_MATRIX;
+  const uint32_t lane = lane_id();
+  const unsigned long long lt = lanemask_lt();
+
+  uint64_t tok_base = 0, sent_base = 0, text_base = 0;
+  if (WRITE) {
+    // rows were sized by pass 1 + scan; skip everything if the output arrays are too
+    // small (the host grows them and re-launches this pass)
+    if (A.totals[0] > A.tok_cap || A.totals[1] > A.sent_cap || A.totals[2] > A.text_cap) return;
+    tok_base = A.tok_off[d]; sent_base = A.sent_off[d]; text_base = A.text_off[d];
+  }
+
+  // wave-uniform carries
+  uint32_t cR = 0;           // runes started before the tile
+  uint32_t cTE = 0, cTS = 0; // token ends / starts before the tile
+  uint32_t cNE = 0, cNSev = 0;  // TextEnd / SentenceEnd calls before the tile
+  uint32_t cNSent = 0;       // sentence ints pushed before the tile
+  uint32_t cSEatEnd = 0, cEatEnd = 0;  // calls seen when the last token ended
+  uint32_t cLastEndR = 0, cLastEndByte = 0;
+  int32_t cLastRend = 0;
+  uint32_t cBase = 0;        // rune index that maps to offset 0 in the current text
+  uint32_t cStartR = 0;      // rune index of the last TOK_START
+  uint32_t cLastER = 0, cLastEByte = 0, cTokAtLastE = 0;
+  bool cHaveE = false;
+  uint32_t status = 0;
+
+  for (uint32_t base = 0; base <= len; base += WAVE) {
+    const uint32_t P = base + lane;
+    uint32_t f = 0, rs = 0, tb = 0;
+    if (P <= len) f = ev[P];
+    if (P < len) {
+      rs = sym[P] >> 15;
+      tb = txt[P];
+    }
+    const unsigned long long mEND = __ballot(f & EV_TOK_END);
+    const unsigned long long mSTART = __ballot(f & EV_TOK_START);
+    const unsigned long long mRS = __ballot(rs);
+    const unsigned long long mEEOT = __ballot(f & EV_E_EOT);
+    const unsigned long long mEEOF = __ballot(f & EV_E_EOF);
+    const unsigned long long mS1 = __ballot(f & EV_S_EOT);
+    const unsigned long long mS2 = __ballot(f & EV_S_EPS);
+    const unsigned long long mS3 = __ballot(f & EV_S_EPS2);
+    const unsigned long long mS4 = __ballot(f & EV_S_EOF);
+    if ((mEND | mSTART | mEEOT | mEEOF | mS1 | mS2 | mS3 | mS4) == 0ull) {
+      cR += popc(mRS);
+      continue;
+    }
+
+    // Order of the calls at one position (bit order): S_EOT, E_EOT, TOK_END,
+    // S_EPS, S_EPS2, S_EOF, E_EOF, TOK_START.
+    const uint32_t R = cR + popc(mRS & lt);
+    const uint32_t te = cTE + popc(mEND & lt);   // tokens ended at lower positions
+    const uint32_t ts = cTS + popc(mSTART & lt);
+    const bool isEnd = (f & EV_TOK_END) != 0;
+    const bool hasEEOT = (f & EV_E_EOT) != 0;
+    const uint32_t s1 = (f & EV_S_EOT) ? 1u : 0u;
+    const uint32_t sLate = popc((unsigned long long)(f & (EV_S_EPS | EV_S_EPS2 | EV_S_EOF)));
+    // TextEnd / SentenceEnd calls fired before this lane's TOK_END (own EOT pair included)
+    const uint32_t eBeforeEnd = cNE + popc(mEEOT & lt) + popc(mEEOF & lt) + (hasEEOT ? 1u : 0u);
+    const uint32_t sBeforeEnd =
+        cNSev + popc(mS1 & lt) + popc(mS2 & lt) + popc(mS3 & lt) + popc(mS4 & lt) + s1;
+    const uint32_t tokLate = te + (isEnd ? 1u : 0u);  // tokens ended before this lane's late calls
+
+    // previous token end (strictly below this lane)
+    const unsigned long long mPrevEnd = mEND & lt;
+    const bool havePrev = mPrevEnd != 0ull;
+    const int jp = havePrev ? highest(mPrevEnd) : 0;
+    const uint32_t seAtPrev_t = __shfl(eBeforeEnd + sBeforeEnd, jp);
+    const uint32_t eAtPrev_t = __shfl(eBeforeEnd, jp);
+    const uint32_t RatPrev_t = __shfl(R, jp);
+    const uint32_t byteAtPrev_t = __shfl(tb, jp);
+    const uint32_t seAtPrev = havePrev ? seAtPrev_t : cSEatEnd;
+    const uint32_t eAtPrev = havePrev ? eAtPrev_t : cEatEnd;
+    const uint32_t RatPrev = havePrev ? RatPrev_t : cLastEndR;
+    const uint32_t byteAtPrev = havePrev ? byteAtPrev_t : cLastEndByte;
+
+    const uint32_t k = te;  // index of the token that ends here
+    const bool text_first = isEnd && (k == 0 || eBeforeEnd > eAtPrev);
+    const bool sent_first = isEnd && (k == 0 || (eBeforeEnd + sBeforeEnd) > seAtPrev);
+
+    // last E_EOT strictly below this lane
+    const unsigned long long mPrevE = mEEOT & lt;
+    const bool haveE = mPrevE != 0ull;
+    const int je = haveE ? highest(mPrevE) : 0;
+    const uint32_t RatE_t = __shfl(R, je);
+    const uint32_t byteAtE_t = __shfl(tb, je);
+    const uint32_t tokAtE_t = __shfl(te, je);  // an E_EOT precedes a token end at its own position
+    const uint32_t RatE = haveE ? RatE_t : cLastER;
+    const uint32_t byteAtE = haveE ? byteAtE_t : cLastEByte;
+    const uint32_t tokAtPrevE = haveE ? tokAtE_t : cTokAtLastE;
+    const bool anyE = haveE || cHaveE;
+
+    // rune index of the matching TOK_START (strictly below: tokens are never empty)
+    const unsigned long long mPrevStart = mSTART & lt;
+    const int js = mPrevStart ? highest(mPrevStart) : 0;
+    const uint32_t Rs_t = __shfl(R, js);
+    const uint32_t Rs = mPrevStart ? Rs_t : cStartR;
+
+    // rune index that counts as offset 0 for the text this token opens
+    // (token_writer.go:66-81: posC restarts at 0; the offset handed to Token is
+    // counted from the start of the window, which the matrix rewinds to the rune
+    // after EOT (matrix.go:601) and the double array only at token flushes).
+    uint32_t base_mine;
+    if (k == 0) {
+      base_mine = (is_matrix && anyE) ? RatE : 0u;
+    } else if (is_matrix) {
+      base_mine = RatE + ((nl_rule && byteAtE == '\n') ? 1u : 0u);
+    } else {
+      base_mine = RatPrev + ((nl_rule && byteAtPrev == '\n') ? 1u : 0u);
+    }
+    const unsigned long long mTF = __ballot(text_first);
+    const unsigned long long mPrevTF = mTF & lt;
+    const int jt = mPrevTF ? highest(mPrevTF) : 0;
+    const uint32_t baseFrom_t = __shfl(base_mine, jt);
+    const uint32_t tbase = text_first ? base_mine : (mPrevTF ? baseFrom_t : cBase);
+    const int32_t rend = (int32_t)(R - tbase);
+    const int32_t rstart = (int32_t)(Rs - tbase);
+
+    // end offset of the last token below this lane / at or below it
+    const int32_t rendPrev_t = __shfl(rend, jp);
+    const int32_t rendBelow = havePrev ? rendPrev_t : cLastRend;
+    const int32_t rendLate = isEnd ? rend : rendBelow;
+
+    // SentenceEnd / TextEnd with no token in the current text (reference panics)
+    const bool emptyEarly = te == tokAtPrevE;                       // for S_EOT, E_EOT
+    const bool emptyLate = hasEEOT ? !isEnd : (tokLate == tokAtPrevE);  // for S_EPS.., E_EOF
+    const uint32_t s1_valid = emptyEarly ? 0u : s1;
+    const uint32_t sLate_valid = emptyLate ? 0u : sLate;
+    if ((s1 && emptyEarly) || (hasEEOT && emptyEarly) || (sLate && emptyLate) ||
+        ((f & EV_E_EOF) && emptyLate))
+      status |= ST_EMPTY_TEXT;
+
+    const uint32_t c = s1_valid + (sent_first ? 1u : 0u) + sLate_valid;
+    uint32_t cTotal;
+    const uint32_t excl = wave_excl_scan(c, cTotal);
+
+    if (WRITE) {
+      if (f & EV_TOK_START) A.tok_bstart[tok_base + ts] = P;
+      if (isEnd) {
+        A.tok_bend[tok_base + k] = P;
+        A.tok_rstart[tok_base + k] = rstart;
+        A.tok_rend[tok_base + k] = rend;
+      }
+      uint64_t si = sent_base + cNSent + excl;
+      if (s1_valid) A.sent[si++] = rendBelow;         // token_writer.go:108
+      if (sent_first) A.sent[si++] = rstart;          // token_writer.go:76-79
+      for (uint32_t q = 0; q < sLate_valid; q++) A.sent[si++] = rendLate;
+      if (hasEEOT) {
+        const uint64_t ti = text_base + eBeforeEnd - 1u;
+        A.text_tok_end[ti] = te;
+        A.text_sent_end[ti] = cNSent + excl + s1_valid;
+      }
+      if (f & EV_E_EOF) {
+        const uint64_t ti = text_base + eBeforeEnd;
+        A.text_tok_end[ti] = tokLate;
+        A.text_sent_end[ti] = cNSent + excl + c;
+      }
+    }
+
+    // carries for the next tile
+    if (mEND) {
+      const int jl = highest(mEND);
+      cSEatEnd = __shfl(eBeforeEnd + sBeforeEnd, jl);
+      cEatEnd = __shfl(eBeforeEnd, jl);
+      cLastEndR = __shfl(R, jl);
+      cLastEndByte = __shfl(tb, jl);
+      cLastRend = __shfl(rend, jl);
+      cBase = __shfl(tbase, jl);
+    }
+    if (mSTART) cStartR = __shfl(R, highest(mSTART));
+    if (mEEOT) {
+      const int jl = highest(mEEOT);
+      cLastER = __shfl(R, jl);
+      cLastEByte = __shfl(tb, jl);
+      cTokAtLastE = __shfl(te, jl);
+      cHaveE = true;
+    }
+    cR += popc(mRS);
+    cTE += popc(mEND);
+    cTS += popc(mSTART);
+    cNE += popc(mEEOT) + popc(mEEOF);
+    cNSev += popc(mS1) + popc(mS2) + popc(mS3) + popc(mS4);
+    cNSent += cTotal;
+  }
+
+  const unsigned long long anyst = __ballot(status != 0);
+  if (!WRITE) {
+    uint32_t stw = 0;
+    // OR-reduce status over the wave
+    uint32_t sred = status;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sred |= __shfl_down(sred, o);
+    stw = __shfl(sred, 0);
+    if (lane == 0) {
+      A.tok_off[d] = cTE;
+      A.sent_off[d] = cNSent;
+      A.text_off[d] = cNE;
+      if (anyst) A.status[d] |= stw;
+    }
+  }
+}
+
+// ------------------------------------------------------- exclusive scan (x3)
+//
+// Turns the per-document counts into CSR row offsets (in place, totals at
+// [n_docs]) and counts flagged documents.  One 1024-thread block; each thread
+// owns a contiguous slice, a block-level scan links the slices.
+
+__global__ __launch_bounds__(1024) void k_scan3(uint64_t *a, uint64_t *b, uint64_t *c, uint32_t n,
+                                                uint64_t *totals, const uint32_t *status) {
+  __shared__ uint64_t sh[3][1024];
+  __shared__ uint32_t shf[1024];
+  const uint32_t T = blockDim.x, tid = threadIdx.x;
+  const uint32_t per = (n + T - 1) / T;
+  const uint32_t lo = tid * per < n ? tid * per : n;
+  const uint32_t hi = lo + per < n ? lo + per : n;
+  uint64_t sa = 0, sb = 0, sc = 0;
+  uint32_t fl = 0;
+  for (uint32_t i = lo; i < hi; i++) { sa += a[i]; sb += b[i]; sc += c[i]; fl += status[i] != 0; }
+  sh[0][tid] = sa; sh[1][tid] = sb; sh[2][tid] = sc; shf[tid] = fl;
+  __syncthreads();
+  for (uint32_t o = 1; o < T; o <<= 1) {
+    uint64_t xa = 0, xb = 0, xc = 0; uint32_t xf = 0;
+    if (tid >= o) { xa = sh[0][tid - o]; xb = sh[1][tid - o]; xc = sh[2][tid - o]; xf = shf[tid - o]; }
+    __syncthreads();
+    sh[0][tid] += xa; sh[1][tid] += xb; sh[2][tid] += xc; shf[tid] += xf;
+    __syncthreads();
+  }
+  uint64_t ra = sh[0][tid] - sa, rb = sh[1][tid] - sb, rc = sh[2][tid] - sc;
+  for (uint32_t i = lo; i < hi; i++) {
+    uint64_t va = a[i], vb = b[i], vc = c[i];
+    a[i] = ra; b[i] = rb; c[i] = rc;
+    ra += va; rb += vb; rc += vc;
+  }
+  if (tid == T - 1) {
+    a[n] = sh[0][tid]; b[n] = sh[1][tid]; c[n] = sh[2][tid];
+    totals[0] = sh[0][tid]; totals[1] = sh[1][tid]; totals[2] = sh[2][tid];
+    totals[3] = shf[tid];
+  }
+}
+
+// ---------------------------------------------------------------- launchers
+
+extern "C" int dtk_launch_symbolize(const uint8_t *text, const uint64_t *doc_off, uint32_t n_docs,
+                                    uint64_t total, const DtkSigmaDev *sig, uint16_t *sym, void *stream) {
+  if (total == 0 || n_docs == 0) return 0;
+  const uint64_t threads = (total + SYM_PER_THREAD - 1) / SYM_PER_THREAD;
+  const uint32_t blocks = (uint32_t)((threads + 255) / 256);
+  hipLaunchKernelGGL(k_symbolize, dim3(blocks), dim3(256), 0, (hipStream_t)stream, text, doc_off, n_docs,
+                     total, *sig, sym);
+  return (int)hipGetLastError();
+}
+
+extern "C" int dtk_launch_walk(const DtkTableDev *tab, const DtkWalkArgs *args, void *stream) {
+  if (args->n_docs == 0) return 0;
+  const uint32_t blocks = (args->n_docs + WAVE - 1) / WAVE;
+  hipStream_t s = (hipStream_t)stream;
+  if (tab->kind == DTK_KIND_MATRIX) {
+    if (tab->entry_bytes == 2) {
+      MatrixTrans<uint16_t> tr{(const uint16_t *)tab->tab, tab->stride, tab->n_eps, tab->start};
+      hipLaunchKernelGGL((k_walk<MatrixTrans<uint16_t>, true>), dim3(blocks), dim3(WAVE), 0, s, tr, *args,
+                         tab->epsilon, tab->unknown, tab->identity);
+    } else {
+      MatrixTrans<uint32_t> tr{(const uint32_t *)tab->tab, tab->stride, tab->n_eps, tab->start};
+      hipLaunchKernelGGL((k_walk<MatrixTrans<uint32_t>, true>), dim3(blocks), dim3(WAVE), 0, s, tr, *args,
+                         tab->epsilon, tab->unknown, tab->identity);
+    }
+  } else {
+    DaTrans tr{(const uint2 *)tab->tab, tab->da_len, tab->da_size, tab->da_base1};
+    hipLaunchKernelGGL((k_walk<DaTrans, false>), dim3(blocks), dim3(WAVE), 0, s, tr, *args, tab->epsilon,
+                       tab->unknown, tab->identity);
+  }
+  return (int)hipGetLastError();
+}
+
+extern "C" int dtk_launch_compact(const DtkCompactArgs *args, int pass, void *stream) {
+  if (args->n_docs == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (pass == 1)
+    hipLaunchKernelGGL(k_compact<false>, dim3(args->n_docs), dim3(WAVE), 0, s, *args);
+  else
+    hipLaunchKernelGGL(k_compact<true>, dim3(args->n_docs), dim3(WAVE), 0, s, *args);
+  return (int)hipGetLastError();
+}
+
+extern "C" int dtk_launch_scan3(uint64_t *a, uint64_t *b, uint64_t *c, uint32_t n_docs, uint64_t *totals,
+                                const uint32_t *status, void *stream) {
+  hipLaunchKernelGGL(k_scan3, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, b, c, n_docs, totals, status);
+  return (int)hipGetLastError();
+}

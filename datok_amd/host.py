@@ -1,0 +1,344 @@
+"""Host-side mirror of Datok's Go API over the C-ABI (no compute here)."""
+import ctypes as C
+import io
+import sys
+
+import numpy as np
+
+from . import _lib
+from ._lib import ModelInfo, ResultView, Totals, check, lib
+
+# token_writer.go:17-25
+TOKENS, SENTENCES, TOKEN_POS, SENTENCE_POS, NEWLINE_AFTER_EOT = 1, 2, 4, 8, 16
+SIMPLE = TOKENS | SENTENCES
+
+EV_S_EOT, EV_E_EOT, EV_TOK_END, EV_S_EPS, EV_S_EPS2, EV_S_EOF, EV_E_EOF, EV_TOK_START = (
+    1, 2, 4, 8, 16, 32, 64, 128)
+
+
+# ------------------------------------------------------------------ UTF-8 (Go)
+def _decode_runes(b: bytes):
+    """Go's rune iteration: invalid bytes become U+FFFD of width 1."""
+    out, i, n = [], 0, len(b)
+    while i < n:
+        b0 = b[i]
+        r, w = 0xFFFD, 1
+        if b0 < 0x80:
+            r = b0
+        elif 0xC2 <= b0 < 0xE0:
+            if i + 1 < n and (b[i + 1] & 0xC0) == 0x80:
+                r, w = ((b0 & 0x1F) << 6) | (b[i + 1] & 0x3F), 2
+        elif 0xE0 <= b0 < 0xF0:
+            lo, hi = (0xA0 if b0 == 0xE0 else 0x80), (0x9F if b0 == 0xED else 0xBF)
+            if i + 2 < n and lo <= b[i + 1] <= hi and (b[i + 2] & 0xC0) == 0x80:
+                r, w = ((b0 & 0x0F) << 12) | ((b[i + 1] & 0x3F) << 6) | (b[i + 2] & 0x3F), 3
+        elif 0xF0 <= b0 <= 0xF4:
+            lo, hi = (0x90 if b0 == 0xF0 else 0x80), (0x8F if b0 == 0xF4 else 0xBF)
+            if (i + 3 < n and lo <= b[i + 1] <= hi and (b[i + 2] & 0xC0) == 0x80
+                    and (b[i + 3] & 0xC0) == 0x80):
+                r, w = (((b0 & 0x07) << 18) | ((b[i + 1] & 0x3F) << 12)
+                        | ((b[i + 2] & 0x3F) << 6) | (b[i + 3] & 0x3F)), 4
+        out.append(r)
+        i += w
+    return out
+
+
+def _runes_to_bytes(runes):
+    return "".join(chr(r) if not (0xD800 <= r <= 0xDFFF or r > 0x10FFFF) else "�"
+                   for r in runes).encode("utf-8")
+
+
+# ----------------------------------------------------------------- TokenWriter
+class TokenWriter:
+    """token_writer.go:27-33: four closures."""
+    __slots__ = ("SentenceEnd", "TextEnd", "Flush", "Token")
+
+
+def new_token_writer(w, flags) -> TokenWriter:
+    """token_writer.go:36-175 NewTokenWriter. `w` is a binary file-like object."""
+    st = {"posC": 0, "pos": [], "sentB": True, "sent": [], "init": True}
+    out = bytearray()
+    tw = TokenWriter()
+
+    def flush():
+        if out:
+            w.write(bytes(out))
+            out.clear()
+        if hasattr(w, "flush"):
+            w.flush()
+
+    def surface(offset, buf):
+        out.extend(_runes_to_bytes(buf[offset:]))
+        out.append(10)
+
+    if flags & (TOKEN_POS | SENTENCE_POS):
+        def token(offset, buf):
+            if st["posC"] == 0 and flags & NEWLINE_AFTER_EOT and buf and buf[0] == 10 and not st["init"]:
+                st["posC"] -= 1
+            st["init"] = False
+            st["posC"] += offset
+            st["pos"].append(st["posC"])
+            if st["sentB"]:
+                st["sentB"] = False
+                st["sent"].append(st["posC"])
+            st["posC"] += len(buf) - offset
+            st["pos"].append(st["posC"])
+            if flags & TOKENS:
+                surface(offset, buf)
+    elif flags & TOKENS:
+        token = surface
+    else:
+        def token(offset, buf):
+            pass
+    tw.Token = token
+
+    if flags & SENTENCE_POS:
+        def sentence_end(_):
+            st["sent"].append(st["pos"][-1])     # Go panics on an empty pos
+            st["sentB"] = True
+            if flags & SENTENCES:
+                out.append(10)
+    elif flags & SENTENCES:
+        def sentence_end(_):
+            out.append(10)
+            flush()
+    else:
+        def sentence_end(_):
+            pass
+    tw.SentenceEnd = sentence_end
+
+    if flags & (TOKEN_POS | SENTENCE_POS):
+        def text_end(_):
+            if flags & TOKEN_POS:
+                out.extend(" ".join(map(str, st["pos"])).encode() if st["pos"] else b"")
+                st["pos"][0]                      # Go: pos[0] panics on an empty text
+                out.append(10)
+            if flags & SENTENCE_POS:
+                st["sent"][0]
+                out.extend(" ".join(map(str, st["sent"])).encode())
+                out.append(10)
+                st["sent"] = []
+                st["sentB"] = True
+            flush()
+            st["posC"] = 0
+            st["pos"] = []
+    else:
+        def text_end(_):
+            out.append(10)
+            flush()
+    tw.TextEnd = text_end
+    tw.Flush = flush
+    return tw
+
+
+def replay(is_matrix, text: bytes, events, tw: TokenWriter):
+    """Feeds one document's event bytes to the closures in reference call order.
+
+    Int arguments as upstream: the matrix passes buffc (matrix.go:575,597,600,684,691);
+    the double array 0, except SentenceEnd(buffc) at EOT (datok.go:1015,1023,1026)."""
+    n = len(text)
+    B = start = 0
+    nz = np.flatnonzero(np.asarray(events[:n + 1]))
+    for p in nz.tolist():
+        e = int(events[p])
+        def buffc():
+            return len(_decode_runes(text[B:p]))
+        if e & EV_S_EOT:
+            tw.SentenceEnd(buffc())
+        if e & EV_E_EOT:
+            tw.TextEnd(buffc() if is_matrix else 0)
+            if is_matrix:
+                B = p
+        if e & EV_TOK_END:
+            buf = _decode_runes(text[B:p])
+            tw.Token(len(_decode_runes(text[B:start])), buf)
+            B = p
+        for bit in (EV_S_EPS, EV_S_EPS2, EV_S_EOF):
+            if e & bit:
+                tw.SentenceEnd(buffc() if is_matrix else 0)
+        if e & EV_E_EOF:
+            tw.TextEnd(buffc() if is_matrix else 0)
+        if e & EV_TOK_START:
+            start = p
+
+
+# ------------------------------------------------------------------- Tokenizer
+class Tokenizer:
+    """fomafile.go:29-33 Tokenizer, backed by a device-resident model."""
+
+    def __init__(self, handle):
+        self._h = handle
+        info = ModelInfo()
+        check(lib().dtk_model_get_info(self._h, C.byref(info)))
+        self.info = {k: getattr(info, k) for k, _ in ModelInfo._fields_}
+        self.last_status = 0
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib().dtk_model_free(h)
+
+    def type(self) -> str:
+        """matrix.go:102 / datok.go:252"""
+        return lib().dtk_model_type(self._h).decode()
+
+    def transduce(self, r, w) -> bool:
+        """matrix.go:340-342: TransduceTokenWriter(r, NewTokenWriter(w, SIMPLE))."""
+        return self.transduce_token_writer(r, new_token_writer(w, SIMPLE))
+
+    def transduce_token_writer(self, r, tw: TokenWriter) -> bool:
+        """matrix.go:348-698 / datok.go:781-1135. One reader = one document."""
+        text = r.read() if hasattr(r, "read") else bytes(r)
+        if isinstance(text, str):
+            text = text.encode("utf-8")
+        try:
+            with Batch(max(len(text), 1), 1) as b:
+                b.set_input(np.frombuffer(text, dtype=np.uint8), np.array([0, len(text)], dtype=np.uint64))
+                b.run(self, 0)
+                res = b.result()
+        except _lib.DatokGpuError as e:        # the reference returns false
+            print("datok_amd:", e, file=sys.stderr)
+            return False
+        self.last_status = int(res.status[0])
+        replay(self.type() == "MATOK", text, res.events, tw)
+        tw.Flush()                              # `defer w.Flush()`, matrix.go:374
+        return True
+
+    def transduce_bytes(self, text: bytes, flags=SIMPLE):
+        """dtk_transduce(): rendering done by the C++ host mirror. Returns (output, status)."""
+        out, n, st = C.c_void_p(), C.c_size_t(), C.c_uint32()
+        check(lib().dtk_transduce(self._h, text, len(text), flags, C.byref(out), C.byref(n), C.byref(st)))
+        try:
+            return C.string_at(out, n.value), st.value
+        finally:
+            lib().dtk_free(out)
+
+
+def load_tokenizer_file(path):
+    """fomafile.go:452-484: returns None (and logs) on any failure."""
+    h = C.c_void_p()
+    rc = lib().dtk_model_load(str(path).encode(), C.byref(h))
+    if rc != _lib.OK:
+        if rc in (_lib.E_NO_DEVICE, _lib.E_HIP):
+            raise _lib.DatokGpuError(rc, "load_tokenizer_file")   # environment, not the file
+        print("datok_amd: %s: %s" % (path, lib().dtk_strerror(rc).decode()), file=sys.stderr)
+        return None
+    return Tokenizer(h)
+
+
+# ----------------------------------------------------------------------- Batch
+class BatchResult:
+    """Host copy of dtk_result_view (CSR over documents)."""
+    __slots__ = ("tok_off", "sent_off", "text_off", "tok_rstart", "tok_rend", "tok_bstart",
+                 "tok_bend", "sent", "text_tok_end", "text_sent_end", "status", "events", "doc_off")
+
+    def doc(self, d):
+        a, b = int(self.tok_off[d]), int(self.tok_off[d + 1])
+        s0, s1 = int(self.sent_off[d]), int(self.sent_off[d + 1])
+        t0, t1 = int(self.text_off[d]), int(self.text_off[d + 1])
+        return dict(tok_rstart=self.tok_rstart[a:b], tok_rend=self.tok_rend[a:b],
+                    tok_bstart=self.tok_bstart[a:b], tok_bend=self.tok_bend[a:b],
+                    sent=self.sent[s0:s1], text_tok_end=self.text_tok_end[t0:t1],
+                    text_sent_end=self.text_sent_end[t0:t1], status=int(self.status[d]))
+
+
+class Batch:
+    """dtk_batch: device buffers + one HIP stream for many documents per launch."""
+
+    def __init__(self, max_bytes, max_docs):
+        self._h = C.c_void_p()
+        check(lib().dtk_batch_create(int(max_bytes), int(max_docs), C.byref(self._h)), "dtk_batch_create")
+        self._keep = None
+        self.n_docs = 0
+        self.total = 0
+        self._doc_off = None
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib().dtk_batch_free(h)
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def stream(self):
+        return lib().dtk_batch_stream(self._h)
+
+    def set_input(self, text: np.ndarray, doc_off: np.ndarray):
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        doc_off = np.ascontiguousarray(doc_off, dtype=np.uint64)
+        self._keep = (text, doc_off)
+        self.n_docs = len(doc_off) - 1
+        self.total = int(doc_off[-1])
+        self._doc_off = doc_off
+        check(lib().dtk_batch_set_input(self._h, text.ctypes.data, doc_off.ctypes.data, self.n_docs),
+              "dtk_batch_set_input")
+
+    def set_input_device(self, d_text_ptr, d_doc_off_ptr, n_docs, total_bytes, keep=None, doc_off_host=None):
+        """Device-resident input (e.g. torch tensors' data_ptr()); `keep` pins the owners."""
+        self._keep = keep
+        self.n_docs = int(n_docs)
+        self.total = int(total_bytes)
+        self._doc_off = doc_off_host
+        check(lib().dtk_batch_set_input_device(self._h, d_text_ptr, d_doc_off_ptr, self.n_docs, self.total),
+              "dtk_batch_set_input_device")
+
+    def run(self, tok: Tokenizer, flags=0):
+        check(lib().dtk_batch_run(tok._h, self._h, flags), "dtk_batch_run")
+
+    def sync(self):
+        check(lib().dtk_batch_sync(self._h), "dtk_batch_sync")
+
+    def set_profiling(self, enable=True):
+        check(lib().dtk_batch_set_profiling(self._h, int(bool(enable))), "dtk_batch_set_profiling")
+
+    STAGES = ("memset", "symbolize", "walk", "compact1", "scan", "compact2")
+
+    def stage_ms(self):
+        """Milliseconds per stage of the last run (needs set_profiling(True))."""
+        ms = (C.c_float * 6)()
+        check(lib().dtk_batch_stage_ms(self._h, C.byref(ms)), "dtk_batch_stage_ms")
+        return dict(zip(self.STAGES, [float(x) for x in ms]))
+
+    def totals(self):
+        t = Totals()
+        check(lib().dtk_batch_totals(self._h, C.byref(t)), "dtk_batch_totals")
+        return {k: getattr(t, k) for k, _ in Totals._fields_}
+
+    def result_device(self) -> ResultView:
+        v = ResultView()
+        check(lib().dtk_batch_result_device(self._h, C.byref(v)), "dtk_batch_result_device")
+        return v
+
+    def result(self) -> BatchResult:
+        v = ResultView()
+        check(lib().dtk_batch_result_host(self._h, C.byref(v)), "dtk_batch_result_host")
+        t = self.totals()
+        nd = self.n_docs
+
+        def arr(ptr, n, dt):
+            if n == 0:
+                return np.zeros(0, dt)
+            buf = (C.c_char * (n * np.dtype(dt).itemsize)).from_address(ptr)
+            return np.frombuffer(buf, dtype=dt).copy()
+        r = BatchResult()
+        r.tok_off = arr(v.tok_off, nd + 1, np.uint64)
+        r.sent_off = arr(v.sent_off, nd + 1, np.uint64)
+        r.text_off = arr(v.text_off, nd + 1, np.uint64)
+        r.tok_rstart = arr(v.tok_rstart, t["n_tokens"], np.int32)
+        r.tok_rend = arr(v.tok_rend, t["n_tokens"], np.int32)
+        r.tok_bstart = arr(v.tok_bstart, t["n_tokens"], np.uint32)
+        r.tok_bend = arr(v.tok_bend, t["n_tokens"], np.uint32)
+        r.sent = arr(v.sent, t["n_sent"], np.int32)
+        r.text_tok_end = arr(v.text_tok_end, t["n_texts"], np.uint32)
+        r.text_sent_end = arr(v.text_sent_end, t["n_texts"], np.uint32)
+        r.status = arr(v.status, nd, np.uint32)
+        r.events = arr(v.events, self.total + nd, np.uint8)
+        r.doc_off = self._doc_off
+        return r

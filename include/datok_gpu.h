@@ -1,0 +1,193 @@
+/*
+ * datok_gpu.h -- C-ABI of the MI355X batch tokenizer (libdatok_gpu.so).
+ *
+ * This is the drop-in boundary for the one hot path of KorAP/Datok: the
+ * matrix / double-array FSA walk behind
+ *     LoadTokenizerFile            (fomafile.go:452-484)
+ *     Tokenizer.Transduce          (matrix.go:340-342, datok.go:769-771)
+ *     Tokenizer.TransduceTokenWriter (matrix.go:348-698, datok.go:781-1135)
+ *     TokenWriter / NewTokenWriter (token_writer.go:27-33, 36-175)
+ * A cgo shim binds exactly these entry points; the C++ and
+ * Python host mirrors in this repo sit on the same ABI.  Plain pointers and
+ * sizes only: no torch, no HIP types in any signature (a HIP stream is passed
+ * as void*).
+ *
+ * Every compute entry point runs on the GPU.  There is no CPU fallback: if no
+ * HIP device is usable the calls return DTK_E_NO_DEVICE.
+ */
+#ifndef DATOK_GPU_H
+#define DATOK_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes (negative); dtk_strerror() renders them ---- */
+enum {
+  DTK_OK = 0,
+  DTK_E_IO = -1,        /* cannot open / read (matrix.go:215-219) */
+  DTK_E_FORMAT = -2,    /* not gzip, bad magic, bad version, short file (matrix.go:253-334) */
+  DTK_E_NO_DEVICE = -3, /* no usable HIP device */
+  DTK_E_HIP = -4,       /* a HIP runtime call failed; dtk_last_hip_error() has the text */
+  DTK_E_ARG = -5,       /* invalid argument */
+  DTK_E_MODEL = -6,     /* model outside device limits (>= 2048 symbols, epsilon cycle, ids out of range) */
+  DTK_E_CAPACITY = -7,  /* batch larger than the dtk_batch was created for */
+  DTK_E_STATE = -8      /* call order (e.g. result requested before a run) */
+};
+
+/* ---- Bits, token_writer.go:17-25 (same values) ---- */
+enum {
+  DTK_TOKENS = 1,
+  DTK_SENTENCES = 2,
+  DTK_TOKEN_POS = 4,
+  DTK_SENTENCE_POS = 8,
+  DTK_NEWLINE_AFTER_EOT = 16,
+  DTK_SIMPLE = 3
+};
+
+/* ---- per-document status bits: inputs on which the reference panics or
+ *      that the device representation cannot express.  Offsets of a document
+ *      with status != 0 are out of contract. ---- */
+enum {
+  DTK_ST_WINDOW_OVERFLOW = 1, /* > 1024 buffered runes: matrix.go:365/406 index panic */
+  DTK_ST_EMPTY_TEXT = 2,      /* SentenceEnd/TextEnd with no token in the text:
+                                 token_writer.go:108,135,145 panic in position modes */
+  DTK_ST_BAD_MODEL = 4,       /* walk left the table */
+  DTK_ST_IRREGULAR = 8,       /* >2 sentence ends at one cursor position, or a text end
+                                 revisited (double array + in-document EOT backtrack) */
+  DTK_ST_STEP_LIMIT = 16      /* safety cap on lookups hit */
+};
+
+typedef struct dtk_model dtk_model;
+typedef struct dtk_batch dtk_batch;
+
+/* ---- devices ---- */
+int dtk_device_count(void);
+int dtk_set_device(int device);          /* device used by subsequent loads / batches of this thread */
+const char *dtk_strerror(int code);
+const char *dtk_last_hip_error(void);
+
+/* ---- model: replaces LoadTokenizerFile (fomafile.go:452-484), LoadMatrixFile
+ *      (matrix.go:214-231), LoadDatokFile (datok.go:600-617).  gunzip, sniff
+ *      "MATOK"/"DATOK", parse, build the device tables.  Immutable afterwards,
+ *      shareable between batches and threads. ---- */
+int dtk_model_load(const char *path, dtk_model **out);
+int dtk_model_load_mem(const void *gz_bytes, size_t n, dtk_model **out); /* ParseMatrix/ParseDatok on a gzip blob */
+void dtk_model_free(dtk_model *m);
+const char *dtk_model_type(const dtk_model *m); /* Tokenizer.Type(): "MATOK" / "DATOK" (matrix.go:102, datok.go:252) */
+
+typedef struct {
+  int32_t kind;          /* 0 matrix, 1 double array */
+  int32_t epsilon, unknown, identity, final_state, sigma_count;
+  uint32_t state_count;  /* matrix: stateCount; double array: array[1].check */
+  uint64_t array_len;    /* matrix: u32 cells; double array: {base,check} pairs */
+  uint32_t n_eps_states; /* states with an epsilon arc */
+  uint32_t max_eps_chain;/* longest path of epsilon arcs */
+  uint32_t entry_bytes;  /* device table cell size (2 or 4 matrix, 8 double array) */
+  uint64_t device_bytes; /* HBM held by the model */
+  uint32_t unknown_used; /* 1 if any state has an arc on the unknown symbol */
+} dtk_model_info;
+int dtk_model_get_info(const dtk_model *m, dtk_model_info *out);
+
+/* ---- batch: one data-parallel TransduceTokenWriter over n_docs documents.
+ *      Each document is one reference call with a fresh writer
+ *      (matrix.go:348 / datok.go:781).  A dtk_batch owns its device buffers
+ *      (sized once at creation) and one HIP stream; no allocation happens in
+ *      dtk_batch_run. ---- */
+int dtk_batch_create(uint64_t max_bytes, uint32_t max_docs, dtk_batch **out);
+void dtk_batch_free(dtk_batch *b);
+
+/* Host input: text = concatenated documents, doc_off[n_docs+1] byte offsets
+ * (doc_off[0] == 0).  Copies to the device on the batch's stream. */
+int dtk_batch_set_input(dtk_batch *b, const uint8_t *text, const uint64_t *doc_off, uint32_t n_docs);
+/* Device-resident input (e.g. a torch tensor's data_ptr): no copy is made, the
+ * buffers must stay valid until the run has been synchronised. */
+int dtk_batch_set_input_device(dtk_batch *b, const void *d_text, const void *d_doc_off,
+                               uint32_t n_docs, uint64_t total_bytes);
+
+/* Launches the whole path on the batch's stream (asynchronous):
+ * symbolise -> walk -> count -> scan -> compact.  flags: DTK_NEWLINE_AFTER_EOT
+ * is the only bit that changes the numbers (token_writer.go:66-68). */
+int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags);
+int dtk_batch_sync(dtk_batch *b);
+void *dtk_batch_stream(dtk_batch *b); /* hipStream_t, for event timing by the caller */
+
+/* Optional per-stage timing with HIP events recorded on the batch's stream
+ * around each kernel of dtk_batch_run (no host synchronisation is added).
+ * dtk_batch_stage_ms() synchronises and returns the milliseconds of the last
+ * run: [0] memset [1] symbolise [2] walk [3] compact pass 1 [4] scan
+ * [5] compact pass 2. */
+int dtk_batch_set_profiling(dtk_batch *b, int enable);
+int dtk_batch_stage_ms(dtk_batch *b, float ms[6]);
+
+/* Totals of the last run (synchronises). */
+typedef struct {
+  uint32_t n_docs;
+  uint64_t n_bytes;
+  uint64_t n_tokens;      /* Token calls */
+  uint64_t n_sent;        /* ints in the flat sentence list (token_writer.go:78,108) */
+  uint64_t n_texts;       /* TextEnd calls */
+  uint64_t n_flagged;     /* documents with status != 0 */
+  uint64_t walk_steps;    /* table lookups performed by the walk kernel */
+} dtk_totals;
+int dtk_batch_totals(dtk_batch *b, dtk_totals *out);
+
+/*
+ * Result arrays of the last run.  CSR over documents:
+ *   tokens of doc d:  [tok_off[d], tok_off[d+1])
+ *     tok_rstart/tok_rend : rune offsets relative to the current text, exactly the
+ *                           pos[] pairs of token_writer.go:72-81
+ *     tok_bstart/tok_bend : byte offsets relative to the document (surface slices)
+ *   sentence ints of d: [sent_off[d], sent_off[d+1])  -- the flat sent[] list of
+ *                           token_writer.go:75-79,104-109 (start of first token after a
+ *                           sentence/text end, end of last token at a SentenceEnd)
+ *   texts of d:        [text_off[d], text_off[d+1])   -- one per TextEnd:
+ *     text_tok_end[i]  = tokens of the document emitted before it
+ *     text_sent_end[i] = sentence ints emitted before it
+ *   status[d]          = DTK_ST_* bits
+ * Pointers are DEVICE pointers owned by the batch, valid until the next run.
+ */
+typedef struct {
+  const uint64_t *tok_off, *sent_off, *text_off; /* n_docs+1 each */
+  const int32_t *tok_rstart, *tok_rend;
+  const uint32_t *tok_bstart, *tok_bend;
+  const int32_t *sent;
+  const uint32_t *text_tok_end, *text_sent_end;
+  const uint32_t *status;
+  /* raw walk output, for replay into TokenWriter closures: one byte per byte
+   * position of every document plus one (index doc_off[d] + d + p) */
+  const uint8_t *events;
+} dtk_result_view;
+int dtk_batch_result_device(dtk_batch *b, dtk_result_view *out);
+/* Copies the arrays to host memory owned by the batch (valid until the next
+ * run / free) and returns host pointers in the same struct. */
+int dtk_batch_result_host(dtk_batch *b, dtk_result_view *out);
+
+/* event byte layout of dtk_result_view.events (chronological order = bit order) */
+enum {
+  DTK_EV_S_EOT = 1,      /* SentenceEnd fired by the EOT rune before this byte (matrix.go:595-598) */
+  DTK_EV_E_EOT = 2,      /* TextEnd fired by that EOT rune (matrix.go:599-600) */
+  DTK_EV_TOK_END = 4,    /* a token ends before this byte */
+  DTK_EV_S_EPS = 8,      /* SentenceEnd from an epsilon arc on an empty token (matrix.go:574-575) */
+  DTK_EV_S_EPS2 = 16,    /* a second one at the same cursor */
+  DTK_EV_S_EOF = 32,     /* final SentenceEnd (matrix.go:683-684) */
+  DTK_EV_E_EOF = 64,     /* final TextEnd (matrix.go:690-691) */
+  DTK_EV_TOK_START = 128 /* a token starts at this byte */
+};
+
+/* ---- drop-in for Tokenizer.Transduce / TransduceTokenWriter with a stock
+ *      NewTokenWriter(w, bits): renders what the reference writes to w for ONE
+ *      stream (the walk runs on the GPU, the rendering of the returned offsets
+ *      is host code, token_writer.go:36-175).  *out is malloc'd; free with
+ *      dtk_free.  Returns 0 (the reference's `true`) or a negative code. ---- */
+int dtk_transduce(const dtk_model *m, const uint8_t *text, size_t n, uint32_t bits,
+                  char **out, size_t *out_len, uint32_t *status);
+void dtk_free(void *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
