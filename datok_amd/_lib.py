@@ -19,7 +19,7 @@ EXPORTS = [
     "dtk_model_load", "dtk_model_load_mem", "dtk_model_free", "dtk_model_type", "dtk_model_get_info",
     "dtk_batch_create", "dtk_batch_free", "dtk_batch_set_input", "dtk_batch_set_input_device",
     "dtk_batch_run", "dtk_batch_sync", "dtk_batch_stream", "dtk_batch_totals",
-    "dtk_batch_set_profiling", "dtk_batch_stage_ms",
+    "dtk_batch_set_profiling", "dtk_batch_stage_ms", "dtk_batch_set_chunking",
     "dtk_batch_result_device", "dtk_batch_result_host", "dtk_transduce", "dtk_free",
 ]
 
@@ -36,7 +36,8 @@ class ModelInfo(C.Structure):
 class Totals(C.Structure):
     _fields_ = [("n_docs", C.c_uint32), ("n_bytes", C.c_uint64), ("n_tokens", C.c_uint64),
                 ("n_sent", C.c_uint64), ("n_texts", C.c_uint64), ("n_flagged", C.c_uint64),
-                ("walk_steps", C.c_uint64)]
+                ("walk_steps", C.c_uint64), ("n_lanes", C.c_uint32), ("chunk_bytes", C.c_uint32),
+                ("repair_rounds", C.c_uint32)]
 
 
 class ResultView(C.Structure):
@@ -44,7 +45,7 @@ class ResultView(C.Structure):
                 ("tok_rstart", C.c_void_p), ("tok_rend", C.c_void_p),
                 ("tok_bstart", C.c_void_p), ("tok_bend", C.c_void_p),
                 ("sent", C.c_void_p), ("text_tok_end", C.c_void_p), ("text_sent_end", C.c_void_p),
-                ("status", C.c_void_p), ("events", C.c_void_p)]
+                ("status", C.c_void_p), ("events", C.c_void_p), ("events_open", C.c_void_p)]
 
 
 class DatokGpuError(RuntimeError):
@@ -104,6 +105,7 @@ def lib():
     L.dtk_batch_stream.restype = vp
     L.dtk_batch_stream.argtypes = [vp]
     L.dtk_batch_totals.argtypes = [vp, C.POINTER(Totals)]
+    L.dtk_batch_set_chunking.argtypes = [vp, u32, u32]
     L.dtk_batch_set_profiling.argtypes = [vp, C.c_int]
     L.dtk_batch_stage_ms.argtypes = [vp, C.POINTER(C.c_float * 6)]
     L.dtk_batch_result_device.argtypes = [vp, C.POINTER(ResultView)]

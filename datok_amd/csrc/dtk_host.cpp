@@ -416,10 +416,23 @@ struct dtk_batch {
   uint64_t total = 0;
   // intermediates
   uint16_t *d_sym = nullptr;
-  uint8_t *d_events = nullptr;
+  uint8_t *d_evA = nullptr, *d_evB = nullptr;  // closing / opening event bytes
   uint32_t *d_status = nullptr;
+  // speculative chunk lanes
+  std::vector<uint64_t> h_doc_off;   // host copy of the document offsets (lane planning)
+  uint32_t cfg_chunk = 0xFFFFFFFFu;  // 0 = one lane per document, 0xFFFFFFFF = automatic
+  uint32_t cfg_warm = 64;
+  uint32_t chunk = 0;                // chunk size of the current plan (0 = none)
+  bool plan_valid = false;
+  uint32_t n_lanes = 0, lane_cap = 0;
+  uint32_t *d_lane_doc = nullptr, *d_chunk_off = nullptr, *d_lane_status = nullptr, *d_redo = nullptr;
+  DtkLaneState *d_lane_start = nullptr, *d_lane_end = nullptr;
+  DtkLanePlan *d_lane_plan = nullptr;
+  uint32_t repair_rounds = 0;        // of the last run
+  const dtk_model *last_model = nullptr;
+  uint32_t last_flags = 0;
   uint64_t *d_tok_off = nullptr, *d_sent_off = nullptr, *d_text_off = nullptr;
-  uint64_t *d_totals = nullptr;  // [0..3] scan totals, [4] walk steps
+  uint64_t *d_totals = nullptr;  // [0..3] scan totals, [4] walk steps, [5] documents to repair (u32)
   uint64_t *h_totals = nullptr;  // pinned
   // outputs (grown on demand, never inside a run unless a re-launch is needed)
   uint64_t tok_cap = 0, sent_cap = 0, text_cap = 0;
@@ -436,7 +449,7 @@ struct dtk_batch {
   std::vector<uint64_t> h_tok_off, h_sent_off, h_text_off;
   std::vector<int32_t> h_rstart, h_rend, h_sent;
   std::vector<uint32_t> h_bstart, h_bend, h_ttok, h_tsent, h_status;
-  std::vector<uint8_t> h_events;
+  std::vector<uint8_t> h_events, h_events_b;
 };
 
 static int alloc_outputs(dtk_batch *b, uint64_t tok, uint64_t sent, uint64_t text) {
@@ -485,7 +498,10 @@ extern "C" int dtk_batch_create(uint64_t max_bytes, uint32_t max_docs, dtk_batch
   B_TRY(hipMalloc((void **)&b->d_text_own, max_bytes + pad));
   B_TRY(hipMalloc((void **)&b->d_off_own, ((uint64_t)max_docs + 1) * 8));
   B_TRY(hipMalloc((void **)&b->d_sym, (max_bytes + pad) * 2));
-  B_TRY(hipMalloc((void **)&b->d_events, max_bytes + max_docs + pad));
+  B_TRY(hipMalloc((void **)&b->d_evA, max_bytes + max_docs + pad));
+  B_TRY(hipMalloc((void **)&b->d_evB, max_bytes + max_docs + pad));
+  B_TRY(hipMalloc((void **)&b->d_redo, (uint64_t)max_docs * 4));
+  B_TRY(hipMalloc((void **)&b->d_chunk_off, ((uint64_t)max_docs + 1) * 4));
   B_TRY(hipMalloc((void **)&b->d_status, (uint64_t)max_docs * 4));
   B_TRY(hipMalloc((void **)&b->d_tok_off, ((uint64_t)max_docs + 1) * 8));
   B_TRY(hipMalloc((void **)&b->d_sent_off, ((uint64_t)max_docs + 1) * 8));
@@ -504,7 +520,9 @@ extern "C" int dtk_batch_create(uint64_t max_bytes, uint32_t max_docs, dtk_batch
 extern "C" void dtk_batch_free(dtk_batch *b) {
   if (!b) return;
   if (b->stream) (void)hipStreamSynchronize(b->stream);
-  void *ptrs[] = {b->d_text_own, b->d_off_own, b->d_sym, b->d_events, b->d_status, b->d_tok_off,
+  void *ptrs[] = {b->d_text_own, b->d_off_own, b->d_sym, b->d_evA, b->d_evB, b->d_redo, b->d_chunk_off,
+                  b->d_lane_doc, b->d_lane_status, b->d_lane_start, b->d_lane_end, b->d_lane_plan,
+                  b->d_status, b->d_tok_off,
                   b->d_sent_off, b->d_text_off, b->d_totals, b->d_rstart, b->d_rend, b->d_sent,
                   b->d_bstart, b->d_bend, b->d_ttok, b->d_tsent};
   for (void *p : ptrs)
@@ -537,6 +555,8 @@ extern "C" int dtk_batch_set_input(dtk_batch *b, const uint8_t *text, const uint
   b->n_docs = n_docs;
   b->total = total;
   b->ran = false;
+  b->h_doc_off.assign(doc_off, doc_off + n_docs + 1);
+  b->plan_valid = false;
   return DTK_OK;
 }
 
@@ -549,7 +569,99 @@ extern "C" int dtk_batch_set_input_device(dtk_batch *b, const void *d_text, cons
   b->n_docs = n_docs;
   b->total = total_bytes;
   b->ran = false;
+  // lane planning needs the offsets on the host: one copy per input, not per run
+  b->h_doc_off.resize((size_t)n_docs + 1);
+  HIP_TRY(hipMemcpy(b->h_doc_off.data(), d_doc_off, ((size_t)n_docs + 1) * 8, hipMemcpyDeviceToHost));
+  if (b->h_doc_off[0] != 0 || b->h_doc_off[n_docs] != total_bytes) return DTK_E_ARG;
+  for (uint32_t d = 0; d < n_docs; d++)
+    if (b->h_doc_off[d + 1] < b->h_doc_off[d] || b->h_doc_off[d + 1] - b->h_doc_off[d] >= 0x7FFFFFF0ull)
+      return DTK_E_ARG;
+  b->plan_valid = false;
   return DTK_OK;
+}
+
+extern "C" int dtk_batch_set_chunking(dtk_batch *b, uint32_t chunk_bytes, uint32_t warm_bytes) {
+  if (!b) return DTK_E_ARG;
+  if (chunk_bytes != 0 && chunk_bytes != 0xFFFFFFFFu && chunk_bytes < 16) return DTK_E_ARG;
+  b->cfg_chunk = chunk_bytes;
+  b->cfg_warm = warm_bytes;
+  b->plan_valid = false;
+  return DTK_OK;
+}
+
+// Splits the documents into chunk lanes (host side of the speculative walk).
+static int plan_lanes(dtk_batch *b) {
+  if (b->plan_valid) return DTK_OK;
+  uint32_t C = b->cfg_chunk;
+  if (C == 0xFFFFFFFFu) {
+    // enough lanes to give every SIMD of the chip a few waves, but chunks no shorter than
+    // a few warm-ups: 256 CUs x 4 SIMDs x 64 lanes = 65536 lanes per "wave per SIMD"
+    const uint64_t want_lanes = 4ull * 65536ull;
+    uint64_t c = b->total / want_lanes;
+    uint32_t p2 = 128;
+    while (p2 < c && p2 < 4096) p2 <<= 1;
+    C = p2;
+  }
+  b->chunk = C;
+  if (C == 0) { b->n_lanes = 0; b->plan_valid = true; return DTK_OK; }
+  const uint32_t nd = b->n_docs;
+  std::vector<uint32_t> chunk_off((size_t)nd + 1);
+  uint64_t lanes = 0;
+  for (uint32_t d = 0; d < nd; d++) {
+    chunk_off[d] = (uint32_t)lanes;
+    const uint64_t len = b->h_doc_off[d + 1] - b->h_doc_off[d];
+    lanes += len ? (len + C - 1) / C : 1;
+    if (lanes >= 0x7FFFFFFFull) return DTK_E_CAPACITY;
+  }
+  chunk_off[nd] = (uint32_t)lanes;
+  std::vector<uint32_t> lane_doc((size_t)lanes);
+  for (uint32_t d = 0; d < nd; d++)
+    for (uint32_t L = chunk_off[d]; L < chunk_off[d + 1]; L++) lane_doc[L] = d;
+  if (lanes > b->lane_cap) {
+    void *old[] = {b->d_lane_doc, b->d_lane_status, b->d_lane_start, b->d_lane_end, b->d_lane_plan};
+    for (void *p : old)
+      if (p) HIP_TRY(hipFree(p));
+    b->d_lane_doc = b->d_lane_status = nullptr;
+    b->d_lane_start = b->d_lane_end = nullptr;
+    b->d_lane_plan = nullptr;
+    const uint64_t cap = lanes + lanes / 8 + 64;
+    HIP_TRY(hipMalloc((void **)&b->d_lane_doc, cap * 4));
+    HIP_TRY(hipMalloc((void **)&b->d_lane_status, cap * 4));
+    HIP_TRY(hipMalloc((void **)&b->d_lane_start, cap * sizeof(DtkLaneState)));
+    HIP_TRY(hipMalloc((void **)&b->d_lane_end, cap * sizeof(DtkLaneState)));
+    HIP_TRY(hipMalloc((void **)&b->d_lane_plan, cap * sizeof(DtkLanePlan)));
+    b->lane_cap = (uint32_t)cap;
+  }
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  HIP_TRY(hipMemcpy(b->d_lane_doc, lane_doc.data(), lanes * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(b->d_chunk_off, chunk_off.data(), ((size_t)nd + 1) * 4, hipMemcpyHostToDevice));
+  b->n_lanes = (uint32_t)lanes;
+  b->plan_valid = true;
+  return DTK_OK;
+}
+
+static DtkWalkArgs walk_args(dtk_batch *b) {
+  DtkWalkArgs w{};
+  w.sym = b->d_sym; w.doc_off = b->d_off; w.n_docs = b->n_docs;
+  w.evA = b->d_evA; w.evB = b->d_evB; w.status = b->d_status;
+  w.steps = (unsigned long long *)(b->d_totals + 4);
+  w.step_factor = 2048;  // look-ahead is bounded by the 1024-rune window (matrix.go:365)
+  return w;
+}
+
+static DtkSpecArgs spec_args(dtk_batch *b, bool redo) {
+  DtkSpecArgs s{};
+  s.n_lanes = b->n_lanes; s.chunk = b->chunk; s.warm = b->cfg_warm;
+  s.lane_doc = b->d_lane_doc; s.chunk_off = b->d_chunk_off;
+  s.lane_start = b->d_lane_start; s.lane_end = b->d_lane_end; s.lane_plan = b->d_lane_plan;
+  s.lane_status = b->d_lane_status;
+  s.redo_from = redo ? b->d_redo : nullptr;
+  return s;
+}
+
+static uint32_t cmp_mask_of(const dtk_model *m) {
+  // the sticky `ok` only matters where an arc on the unknown symbol exists (matrix.go:478-485)
+  return LANE_F_SENT | LANE_F_TEXT | (m->unknown_used ? LANE_F_OK : 0u);
 }
 
 static int launch_compact2(dtk_batch *b) {
@@ -567,26 +679,36 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
   if (!m || !b) return DTK_E_ARG;
   if (b->n_docs == 0 || !b->d_off) return DTK_E_STATE;
   if (m->device != b->device) return DTK_E_ARG;
+  int prc = plan_lanes(b);
+  if (prc != DTK_OK) return prc;
+  b->last_model = m;
+  b->last_flags = flags;
+  b->repair_rounds = 0;
   hipStream_t s = b->stream;
   const bool prof = b->profiling;
 #define STAGE(i) do { if (prof) HIP_TRY(hipEventRecord(b->ev[i], s)); } while (0)
   STAGE(0);
-  HIP_TRY(hipMemsetAsync(b->d_events, 0, b->total + b->n_docs, s));
+  HIP_TRY(hipMemsetAsync(b->d_evA, 0, b->total + b->n_docs, s));
+  HIP_TRY(hipMemsetAsync(b->d_evB, 0, b->total + b->n_docs, s));
   HIP_TRY(hipMemsetAsync(b->d_totals, 0, 8 * 8, s));
   STAGE(1);
   if (dtk_launch_symbolize(b->d_text, b->d_off, b->n_docs, b->total, &m->sig, b->d_sym, s))
     return hip_fail(hipGetLastError(), "symbolize");
   STAGE(2);
-  DtkWalkArgs w{};
-  w.sym = b->d_sym; w.doc_off = b->d_off; w.n_docs = b->n_docs;
-  w.events = b->d_events; w.status = b->d_status;
-  w.steps = (unsigned long long *)(b->d_totals + 4);
-  w.step_factor = 2048;  // look-ahead is bounded by the 1024-rune window (matrix.go:365)
-  if (dtk_launch_walk(&m->tab, &w, s)) return hip_fail(hipGetLastError(), "walk");
+  DtkWalkArgs w = walk_args(b);
+  if (b->chunk == 0) {
+    if (dtk_launch_walk(&m->tab, &w, s)) return hip_fail(hipGetLastError(), "walk");
+  } else {
+    DtkSpecArgs sp = spec_args(b, false);
+    uint32_t *n_bad = (uint32_t *)(b->d_totals + 5);
+    for (int stage = 0; stage < 4; stage++)
+      if (dtk_launch_spec(&m->tab, &w, &sp, stage, cmp_mask_of(m), b->d_redo, n_bad, s))
+        return hip_fail(hipGetLastError(), "speculative walk");
+  }
   STAGE(3);
   DtkCompactArgs c{};
   c.text = b->d_text; c.sym = b->d_sym; c.doc_off = b->d_off; c.n_docs = b->n_docs;
-  c.events = b->d_events; c.status = b->d_status;
+  c.evA = b->d_evA; c.evB = b->d_evB; c.status = b->d_status;
   c.flags = flags & DTK_NEWLINE_AFTER_EOT; c.kind = m->kind;
   c.tok_off = b->d_tok_off; c.sent_off = b->d_sent_off; c.text_off = b->d_text_off;
   c.totals = b->d_totals;
@@ -634,6 +756,34 @@ static int finish(dtk_batch *b) {
   if (!b->ran) return DTK_E_STATE;
   if (b->totals_valid) return DTK_OK;
   HIP_TRY(hipStreamSynchronize(b->stream));
+  // Speculation check failed somewhere: repair those documents from their first bad lane
+  // on (clear, re-plan, re-walk, re-check) until every lane chains, then compact again.
+  if (b->chunk != 0 && (uint32_t)b->h_totals[5] != 0) {
+    const dtk_model *m = b->last_model;
+    hipStream_t s = b->stream;
+    DtkWalkArgs w = walk_args(b);
+    uint32_t *n_bad = (uint32_t *)(b->d_totals + 5);
+    while ((uint32_t)b->h_totals[5] != 0) {
+      b->repair_rounds++;
+      DtkSpecArgs sp = spec_args(b, true);
+      HIP_TRY(hipMemsetAsync(n_bad, 0, 8, s));
+      const int order[4] = {4, 1, 2, 3};
+      for (int stage : order)
+        if (dtk_launch_spec(&m->tab, &w, &sp, stage, cmp_mask_of(m), b->d_redo, n_bad, s))
+          return hip_fail(hipGetLastError(), "speculative repair");
+      HIP_TRY(hipMemcpyAsync(b->h_totals + 5, b->d_totals + 5, 8, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      if (b->repair_rounds > 1000000u) return DTK_E_STATE;
+    }
+    DtkCompactArgs c = b->last_args;
+    if (dtk_launch_compact(&c, 1, s)) return hip_fail(hipGetLastError(), "compact pass 1");
+    if (dtk_launch_scan3(b->d_tok_off, b->d_sent_off, b->d_text_off, b->n_docs, b->d_totals, b->d_status, s))
+      return hip_fail(hipGetLastError(), "scan");
+    int rc = launch_compact2(b);
+    if (rc != DTK_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(b->h_totals, b->d_totals, 5 * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
   const uint64_t nt = b->h_totals[0], ns = b->h_totals[1], nx = b->h_totals[2];
   if (nt > b->tok_cap || ns > b->sent_cap || nx > b->text_cap) {
     int rc = alloc_outputs(b, nt + nt / 8 + 16, ns + ns / 8 + 16, nx + nx / 8 + 16);
@@ -649,6 +799,9 @@ static int finish(dtk_batch *b) {
   b->totals.n_texts = nx;
   b->totals.n_flagged = b->h_totals[3];
   b->totals.walk_steps = b->h_totals[4];
+  b->totals.n_lanes = b->chunk ? b->n_lanes : b->n_docs;
+  b->totals.chunk_bytes = b->chunk;
+  b->totals.repair_rounds = b->repair_rounds;
   b->totals_valid = true;
   return DTK_OK;
 }
@@ -669,7 +822,7 @@ extern "C" int dtk_batch_result_device(dtk_batch *b, dtk_result_view *o) {
   o->tok_rstart = b->d_rstart; o->tok_rend = b->d_rend;
   o->tok_bstart = b->d_bstart; o->tok_bend = b->d_bend;
   o->sent = b->d_sent; o->text_tok_end = b->d_ttok; o->text_sent_end = b->d_tsent;
-  o->status = b->d_status; o->events = b->d_events;
+  o->status = b->d_status; o->events = b->d_evA; o->events_open = b->d_evB;
   return DTK_OK;
 }
 
@@ -694,12 +847,13 @@ extern "C" int dtk_batch_result_host(dtk_batch *b, dtk_result_view *o) {
   if ((rc = get(b->h_ttok, b->d_ttok, nx))) return rc;
   if ((rc = get(b->h_tsent, b->d_tsent, nx))) return rc;
   if ((rc = get(b->h_status, b->d_status, nd))) return rc;
-  if ((rc = get(b->h_events, b->d_events, b->total + nd))) return rc;
+  if ((rc = get(b->h_events, b->d_evA, b->total + nd))) return rc;
+  if ((rc = get(b->h_events_b, b->d_evB, b->total + nd))) return rc;
   o->tok_off = b->h_tok_off.data(); o->sent_off = b->h_sent_off.data(); o->text_off = b->h_text_off.data();
   o->tok_rstart = b->h_rstart.data(); o->tok_rend = b->h_rend.data();
   o->tok_bstart = b->h_bstart.data(); o->tok_bend = b->h_bend.data();
   o->sent = b->h_sent.data(); o->text_tok_end = b->h_ttok.data(); o->text_sent_end = b->h_tsent.data();
-  o->status = b->h_status.data(); o->events = b->h_events.data();
+  o->status = b->h_status.data(); o->events = b->h_events.data(); o->events_open = b->h_events_b.data();
   return DTK_OK;
 }
 

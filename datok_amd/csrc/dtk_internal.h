@@ -75,11 +75,45 @@ struct DtkTableDev {
   uint32_t epsilon, unknown, identity;
 };
 
+// ---- speculative chunk lanes
+#define LANE_F_SENT 1u     // sentenceEnd (matrix.go:360)
+#define LANE_F_TEXT 2u     // textEnd (matrix.go:363)
+#define LANE_F_OK 4u       // sticky ok (matrix.go:352)
+#define LANE_F_DROPPED 8u  // the lane produced an event outside its window
+#define LANE_F_IDLE 16u
+enum { PLAN_OFF = 0, PLAN_CHAINED = 1, PLAN_LAST = 2 };
+
+// Loop state at a "sync point" = right after the reference rewinds its window
+// (matrix.go:537-543, 608-627): nothing else survives a rewind.
+struct DtkLaneState {
+  uint32_t p;      // byte position in the document; 0xFFFFFFFF = none / ran to EOF
+  uint32_t t;      // automaton state
+  uint32_t aux;    // double array: device base word of t
+  uint32_t flags;  // LANE_F_*
+};
+struct DtkLanePlan {
+  uint32_t stop;   // stop at the first sync point at or behind this position
+  uint32_t wend;   // events are stored up to here (the next lane's start position)
+  uint32_t mode;   // PLAN_*
+  uint32_t pad;
+};
+struct DtkSpecArgs {
+  uint32_t n_lanes;
+  uint32_t chunk, warm;             // chunk size C and warm-up overlap W in bytes
+  const uint32_t *lane_doc;         // lane -> document
+  const uint32_t *chunk_off;        // document -> first lane (n_docs + 1)
+  struct DtkLaneState *lane_start;  // record each lane starts from
+  struct DtkLaneState *lane_end;    // where it stopped
+  struct DtkLanePlan *lane_plan;
+  uint32_t *lane_status;
+  const uint32_t *redo_from;        // repair rounds: first lane to redo per document, or null
+};
+
 struct DtkWalkArgs {
   const uint16_t *sym;      // symbol stream, one entry per input byte
   const uint64_t *doc_off;  // n_docs + 1
   uint32_t n_docs;
-  uint8_t *events;          // zero-filled; index doc_off[d] + d + p
+  uint8_t *evA, *evB;       // closing / opening event bytes, zero-filled; index doc_off[d] + d + p
   uint32_t *status;         // per document, OR-ed
   unsigned long long *steps;  // global lookup counter
   uint32_t step_factor;     // cap = step_factor * (len + 2) lookups per document
@@ -90,7 +124,7 @@ struct DtkCompactArgs {
   const uint16_t *sym;
   const uint64_t *doc_off;
   uint32_t n_docs;
-  const uint8_t *events;
+  const uint8_t *evA, *evB;
   uint32_t *status;
   uint32_t flags;           // DTK_NEWLINE_AFTER_EOT
   int kind;                 // matrix / double array (EOT rewind rule differs)
@@ -112,6 +146,9 @@ extern "C" {
 int dtk_launch_symbolize(const uint8_t *text, const uint64_t *doc_off, uint32_t n_docs,
                          uint64_t total, const struct DtkSigmaDev *sig, uint16_t *sym, void *stream);
 int dtk_launch_walk(const struct DtkTableDev *tab, const struct DtkWalkArgs *args, void *stream);
+int dtk_launch_spec(const struct DtkTableDev *tab, const struct DtkWalkArgs *args,
+                    const struct DtkSpecArgs *spec, int stage, uint32_t cmp_mask, uint32_t *redo_out,
+                    uint32_t *n_bad, void *stream);
 int dtk_launch_compact(const struct DtkCompactArgs *args, int pass, void *stream);
 int dtk_launch_scan3(uint64_t *a, uint64_t *b, uint64_t *c, uint32_t n_docs, uint64_t *totals,
                      const uint32_t *status, void *stream);

@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "dtk_internal.h"
 
 #define WAVE 64
@@ -232,182 +234,455 @@ struct DaTrans {
   }
 };
 
-// Event bytes are written lane-privately.  Cursor positions of successive
-// events never decrease for the matrix walk, so one pending byte per lane is
-// enough; the double array can revisit a position (no rewind at EOT,
-// datok.go:1019-1030), which takes the read-modify-write path.
+// Event bytes are written lane-privately.  "Closing" calls (S_EOT, E_EOT,
+// TOK_END: what a rewind of the window fires) and "opening" calls (everything
+// fired after it) live in two byte arrays, so that the lane whose walk ends with
+// a rewind at position q and the lane that starts from q never store to the
+// same byte.  Cursor positions of successive events never decrease for the
+// matrix walk, so one pending byte per array is enough; the double array can
+// revisit a position (no rewind at EOT, datok.go:1019-1030), which takes the
+// read-modify-write path.  A lane only stores inside its window
+//   opening: lo <= pos < hi      closing: lo < pos <= hi
+// (whole document: lo = 0, hi = 0xFFFFFFFF); an event outside is dropped and
+// remembered, the validator then knows the lane left its window.
+#define EV_CLOSING (EV_S_EOT | EV_E_EOT | EV_TOK_END)
+
 struct EventSink {
-  uint8_t *ev;
-  uint32_t cur_p, cur_f, hiw;  // pending position / byte, highest position stored so far
+  uint8_t *evA, *evB;          // closing / opening, index = position in the document
+  uint32_t pA, fA, pB, fB;     // pending position / byte per array
+  uint32_t hiwA, hiwB;         // highest position stored so far (read-modify-write path)
+  uint32_t lo, hi;             // window
   uint32_t st;
-  __device__ __forceinline__ void init(uint8_t *e) { ev = e; cur_p = 0xFFFFFFFFu; cur_f = 0; hiw = 0; st = 0; }
+  bool dropped;
+  __device__ __forceinline__ void init(uint8_t *a, uint8_t *b, uint32_t wlo, uint32_t whi) {
+    evA = a; evB = b; pA = pB = 0xFFFFFFFFu; fA = fB = 0; hiwA = hiwB = 0; lo = wlo; hi = whi; st = 0;
+    dropped = false;
+  }
   __device__ __forceinline__ void flush() {
-    if (cur_p != 0xFFFFFFFFu && cur_f) {
-      ev[cur_p] = (uint8_t)cur_f;
-      if (cur_p > hiw) hiw = cur_p;
-    }
+    if (pA != 0xFFFFFFFFu && fA) evA[pA] = (uint8_t)fA;
+    if (pB != 0xFFFFFFFFu && fB) evB[pB] = (uint8_t)fB;
   }
   template <bool MONOTONIC>
   __device__ __forceinline__ void emit(uint32_t p, uint32_t bit) {
-    if (p != cur_p) {
-      flush();
-      cur_f = 0;
-      if (!MONOTONIC) {
-        if (cur_p != 0xFFFFFFFFu && p <= hiw) cur_f = ev[p];
+    const bool closing = (bit & EV_CLOSING) != 0;
+    if (closing ? !(p > lo && p <= hi) : !(p >= lo && p < hi)) { dropped = true; return; }
+    uint32_t &cp = closing ? pA : pB;
+    uint32_t &cf = closing ? fA : fB;
+    uint32_t &hw = closing ? hiwA : hiwB;
+    uint8_t *ev = closing ? evA : evB;
+    if (p != cp) {
+      if (cp != 0xFFFFFFFFu && cf) {
+        ev[cp] = (uint8_t)cf;
+        if (cp > hw) hw = cp;
       }
-      cur_p = p;
+      cf = 0;
+      if (!MONOTONIC) {
+        if (cp != 0xFFFFFFFFu && p <= hw) cf = ev[p];
+      }
+      cp = p;
     }
-    if (bit == EV_S_EPS && (cur_f & EV_S_EPS)) {
-      if (cur_f & EV_S_EPS2) st |= ST_IRREGULAR;
+    if (bit == EV_S_EPS && (cf & EV_S_EPS)) {
+      if (cf & EV_S_EPS2) st |= ST_IRREGULAR;
       bit = EV_S_EPS2;
-    } else if ((bit & (EV_E_EOT | EV_S_EOT | EV_TOK_END | EV_TOK_START)) && (cur_f & bit)) {
+    } else if ((bit & (EV_E_EOT | EV_S_EOT | EV_TOK_END | EV_TOK_START)) && (cf & bit)) {
       st |= ST_IRREGULAR;
     }
-    cur_f |= bit;
+    cf |= bit;
   }
 };
 
-template <typename TRANS, bool IS_MATRIX>
-__global__ __launch_bounds__(WAVE) void k_walk(TRANS tr, DtkWalkArgs A, uint32_t epsilon,
-                                               uint32_t unknown, uint32_t identity) {
-  const uint32_t d = blockIdx.x * WAVE + threadIdx.x;
-  uint32_t my_steps = 0;
-  if (d < A.n_docs) {
-    const uint64_t off = A.doc_off[d];
-    const uint32_t len = (uint32_t)(A.doc_off[d + 1] - off);
-    const uint16_t *__restrict__ s = A.sym + off;
-    EventSink sink;
-    sink.init(A.events + off + d);
+// What a lane is asked to do.
+enum { MODE_DOC = 0,    // whole document from the initial state, all events
+       MODE_START = 1,  // speculative warm-up: no events, stop at the first rewind at/after stop_pos
+       MODE_CHUNK = 2   // walk from a recorded start, events inside the window, stop at the first
+                        // rewind at/after stop_pos (or run the EOF tail)
+};
 
-    // loop state, named after matrix.go:349-381
-    uint32_t a = 0, t0 = 0, aux0 = 0;
-    uint32_t t = tr.start_state();  // matrix.go:351 `t := uint32(1)`
-    uint32_t aux = tr.start_aux();
-    const uint32_t t_start = t, aux_start = aux;
-    bool ok = false;                         // sticky `ok` of matrix.go:352 / datok.go:785
-    uint32_t eps_t = 0, eps_aux = 0, eps_p = 0, eps_r = 0;  // epsilonState / epsilonOffset
-    bool sentence_end = false, text_end = false;
-    uint32_t p = 0;    // byte position of buffer[buffc]
-    uint32_t tp = 0;   // byte position of buffer[bufft]
-    uint32_t hi = 0;   // byte position behind buffer[buffi-1]: read high-water mark
-    uint32_t rc = 0;   // buffc (runes since the last rewind)
-    uint32_t ri = 0;   // buffi
-    uint32_t w = 1;    // width of the rune at p
-    bool eot = false, newchar = true;
-    uint32_t st = 0;
-    unsigned long long cap64 = (unsigned long long)A.step_factor * ((unsigned long long)len + 2ull);
-    const uint32_t cap = cap64 > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)cap64;
+// The walk of matrix.go:348-698 / datok.go:781-1135 for one lane.
+// Returns through `fin`: p == 0xFFFFFFFF means "ran to EOF" (MODE_START: no
+// rewind found; otherwise: tail done).
+template <typename TRANS, bool IS_MATRIX, int MODE>
+__device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__restrict__ s, uint32_t len,
+                                          DtkLaneState init, uint32_t stop_pos, EventSink &sink,
+                                          uint32_t epsilon, uint32_t unknown, uint32_t identity,
+                                          uint32_t cap, DtkLaneState &fin, uint32_t &st_out,
+                                          uint32_t &steps_out) {
+  // loop state, named after matrix.go:349-381
+  uint32_t a = 0, t0 = 0, aux0 = 0;
+  uint32_t t = init.t, aux = init.aux;  // matrix.go:351 `t := uint32(1)` for MODE_DOC
+  const uint32_t t_start = tr.start_state(), aux_start = tr.start_aux();
+  bool ok = (init.flags & LANE_F_OK) != 0;  // sticky `ok` of matrix.go:352 / datok.go:785
+  uint32_t eps_t = 0, eps_aux = 0, eps_p = 0, eps_r = 0;  // epsilonState / epsilonOffset
+  bool sentence_end = (init.flags & LANE_F_SENT) != 0, text_end = (init.flags & LANE_F_TEXT) != 0;
+  uint32_t p = init.p;   // byte position of buffer[buffc]
+  uint32_t tp = init.p;  // byte position of buffer[bufft]
+  uint32_t hi = init.p;  // byte position behind buffer[buffi-1]: read high-water mark
+  uint32_t rc = 0;       // buffc (runes since the last rewind)
+  uint32_t ri = 0;       // buffi
+  uint32_t w = 1;        // width of the rune at p
+  uint32_t e = 0, e_pos = 0xFFFFFFFFu, e_next = 0;  // symbol entry of position e_pos; prefetched successor
+  bool eot = false, newchar = true;
+  uint32_t st = 0, my_steps = 0;
+  fin.p = 0xFFFFFFFFu; fin.t = 0; fin.aux = 0; fin.flags = 0;
+  bool stopped = false;
 
-    for (;;) {
-      if (newchar) {
-        if (p >= len) {  // p == hi == len: nothing buffered, reader at EOF
-          // reader EOF: the drain of matrix.go:650-668 / datok.go:1085-1103
-          t0 = t; aux0 = aux;
-          a = epsilon;
-          newchar = false;
-          if (tr.has_eps(t0, aux0)) {
-            // goto PARSECHARM with a = epsilon
-          } else if (eps_t != 0) {
-            t0 = eps_t; aux0 = eps_aux;
-            eps_t = 0;
-            p = eps_p; rc = eps_r;
-          } else {
-            break;
-          }
-        } else {
-          const uint32_t e = s[p];
-          a = e & DTK_SYM_MASK;
-          w = ((e >> DTK_SYM_W_SHIFT) & 3u) + 1u;
-          const uint32_t cls = (e >> DTK_SYM_CLS_SHIFT) & 3u;
-          if (p >= hi) {  // a rune not yet in the window (matrix.go:388-408)
-            if (ri >= DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
-            ri++;
-            hi = p + w;
-          }
-          eot = cls == 1u;                 // matrix.go:422
-          if (cls >= 2u) ok = cls == 2u;   // matrix.go:427: only runes >= 256 write `ok`
-          t0 = t; aux0 = aux;              // matrix.go:437
-          if (tr.has_eps(t0, aux0)) {      // matrix.go:442-454
-            eps_t = t0; eps_aux = aux0; eps_p = p; eps_r = rc;
-          }
-        }
-      }
+#define SYNC_POINT()                                                                          \
+  do {                                                                                        \
+    if (MODE != MODE_DOC && p >= stop_pos) {                                                  \
+      fin.p = p; fin.t = t; fin.aux = aux;                                                    \
+      fin.flags = (sentence_end ? LANE_F_SENT : 0u) | (text_end ? LANE_F_TEXT : 0u) |         \
+                  (ok ? LANE_F_OK : 0u);                                                      \
+      stopped = true;                                                                         \
+    }                                                                                         \
+  } while (0)
 
-      bool nontoken = false;
-      const bool good = tr.step(t0, aux0, a, t, aux, nontoken, st);
-      if (++my_steps > cap) { st |= ST_STEP_LIMIT; break; }
-
-      if (!good) {
-        if (!ok && a == identity) {  // matrix.go:478-485
-          a = unknown;
-          newchar = false; eot = false;
-        } else if (a != epsilon && eps_t != 0) {  // matrix.go:487-497
+  for (;;) {
+    if (newchar) {
+      if (p >= len) {  // p == hi == len: nothing buffered, reader at EOF
+        // the drain of matrix.go:650-668 / datok.go:1085-1103
+        t0 = t; aux0 = aux;
+        a = epsilon;
+        newchar = false;
+        if (tr.has_eps(t0, aux0)) {
+          // goto PARSECHARM with a = epsilon
+        } else if (eps_t != 0) {
           t0 = eps_t; aux0 = eps_aux;
           eps_t = 0;
           p = eps_p; rc = eps_r;
-          a = epsilon;
-          newchar = false; eot = false;
-        } else {  // matrix.go:499-552: drop what is buffered as a token, restart at state 1
-          if (a == epsilon) { st |= ST_BAD_MODEL; break; }  // would hand out stale buffer runes
-          if (p <= tp) { p += w; rc++; }                    // matrix.go:515-516
-          sink.emit<IS_MATRIX>(tp, EV_TOK_START);
-          sink.emit<IS_MATRIX>(p, EV_TOK_END);              // matrix.go:528
-          sentence_end = false; text_end = false;
-          ri -= rc; rc = 0; tp = p;                         // matrix.go:537-543
-          eps_t = 0;
-          t = t_start; aux = aux_start;                     // matrix.go:548
-          newchar = true;
-        }
-        continue;
-      }
-
-      bool rewind = false;
-      if (a == epsilon) {  // matrix.go:563-576
-        if (p > tp) {
-          sink.emit<IS_MATRIX>(tp, EV_TOK_START);
-          sink.emit<IS_MATRIX>(p, EV_TOK_END);
-          rewind = true;
-          sentence_end = false; text_end = false;
         } else {
-          sentence_end = true;
-          sink.emit<IS_MATRIX>(p, EV_S_EPS);
+          break;
         }
-      } else {  // matrix.go:579-591
-        const bool first = p == tp;
-        p += w; rc++;
-        if (first && nontoken) tp = p;
+      } else {
+        if (e_pos != p) { e = s[p]; e_pos = p; }  // only after a backtrack / restart
+        a = e & DTK_SYM_MASK;
+        w = ((e >> DTK_SYM_W_SHIFT) & 3u) + 1u;
+        const uint32_t cls = (e >> DTK_SYM_CLS_SHIFT) & 3u;
+        // the successor is fetched while the transition load is in flight
+        e_next = (p + w < len) ? (uint32_t)s[p + w] : 0u;
+        if (p >= hi) {  // a rune not yet in the window (matrix.go:388-408)
+          if (ri >= DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
+          ri++;
+          hi = p + w;
+        }
+        eot = cls == 1u;                 // matrix.go:422
+        if (cls >= 2u) ok = cls == 2u;   // matrix.go:427: only runes >= 256 write `ok`
+        t0 = t; aux0 = aux;              // matrix.go:437
+        if (tr.has_eps(t0, aux0)) {      // matrix.go:442-454
+          eps_t = t0; eps_aux = aux0; eps_p = p; eps_r = rc;
+        }
       }
-      if (eot) {  // matrix.go:593-605 / datok.go:1019-1030
-        eot = false;
-        if (!sentence_end) { sentence_end = true; sink.emit<IS_MATRIX>(p, EV_S_EOT); }
-        text_end = true;
-        sink.emit<IS_MATRIX>(p, EV_E_EOT);
-        if (IS_MATRIX) rewind = true;  // matrix.go:601; the double array keeps its window
-      }
-      if (rewind) {  // matrix.go:608-627
-        ri -= rc; rc = 0; tp = p;
-        eps_t = 0;
-      }
-      newchar = true;
     }
 
-    if (!(st & (ST_STEP_LIMIT | ST_BAD_MODEL))) {
-      if (p > tp) {  // matrix.go:671-678
-        sink.emit<IS_MATRIX>(tp, EV_TOK_START);
-        sink.emit<IS_MATRIX>(p, EV_TOK_END);
+    bool nontoken = false;
+    const bool good = tr.step(t0, aux0, a, t, aux, nontoken, st);
+    if (++my_steps > cap) { st |= ST_STEP_LIMIT; break; }
+
+    if (!good) {
+      if (!ok && a == identity) {  // matrix.go:478-485
+        a = unknown;
+        newchar = false; eot = false;
+      } else if (a != epsilon && eps_t != 0) {  // matrix.go:487-497
+        t0 = eps_t; aux0 = eps_aux;
+        eps_t = 0;
+        p = eps_p; rc = eps_r;
+        a = epsilon;
+        newchar = false; eot = false;
+      } else {  // matrix.go:499-552: drop what is buffered as a token, restart at state 1
+        if (a == epsilon) { st |= ST_BAD_MODEL; break; }  // would hand out stale buffer runes
+        if (p <= tp) { p += w; rc++; e = e_next; e_pos = p; }  // matrix.go:515-516
+        if (MODE != MODE_START) {
+          sink.template emit<IS_MATRIX>(tp, EV_TOK_START);
+          sink.template emit<IS_MATRIX>(p, EV_TOK_END);   // matrix.go:528
+        }
         sentence_end = false; text_end = false;
+        ri -= rc; rc = 0; tp = p;                         // matrix.go:537-543
+        eps_t = 0;
+        t = t_start; aux = aux_start;                     // matrix.go:548
+        newchar = true;
+        SYNC_POINT();
+        if (stopped) break;
       }
-      if (!sentence_end) sink.emit<IS_MATRIX>(p, EV_S_EOF);  // matrix.go:683-684
-      if (!text_end) sink.emit<IS_MATRIX>(p, EV_E_EOF);      // matrix.go:690-691
+      continue;
     }
+
+    bool rewind = false;
+    if (a == epsilon) {  // matrix.go:563-576
+      if (p > tp) {
+        if (MODE != MODE_START) {
+          sink.template emit<IS_MATRIX>(tp, EV_TOK_START);
+          sink.template emit<IS_MATRIX>(p, EV_TOK_END);
+        }
+        rewind = true;
+        sentence_end = false; text_end = false;
+      } else {
+        sentence_end = true;
+        if (MODE != MODE_START) sink.template emit<IS_MATRIX>(p, EV_S_EPS);
+      }
+    } else {  // matrix.go:579-591
+      const bool first = p == tp;
+      p += w; rc++;
+      e = e_next; e_pos = p;
+      if (first && nontoken) tp = p;
+    }
+    if (eot) {  // matrix.go:593-605 / datok.go:1019-1030
+      eot = false;
+      if (!sentence_end) {
+        sentence_end = true;
+        if (MODE != MODE_START) sink.template emit<IS_MATRIX>(p, EV_S_EOT);
+      }
+      text_end = true;
+      if (MODE != MODE_START) sink.template emit<IS_MATRIX>(p, EV_E_EOT);
+      if (IS_MATRIX) rewind = true;  // matrix.go:601; the double array keeps its window
+    }
+    newchar = true;
+    if (rewind) {  // matrix.go:608-627
+      ri -= rc; rc = 0; tp = p;
+      eps_t = 0;
+      SYNC_POINT();
+      if (stopped) break;
+    }
+  }
+#undef SYNC_POINT
+
+  if (!stopped && MODE != MODE_START && !(st & (ST_STEP_LIMIT | ST_BAD_MODEL))) {
+    if (p > tp) {  // matrix.go:671-678
+      sink.template emit<IS_MATRIX>(tp, EV_TOK_START);
+      sink.template emit<IS_MATRIX>(p, EV_TOK_END);
+      sentence_end = false; text_end = false;
+    }
+    if (!sentence_end) sink.template emit<IS_MATRIX>(p, EV_S_EOF);  // matrix.go:683-684
+    if (!text_end) sink.template emit<IS_MATRIX>(p, EV_E_EOF);      // matrix.go:690-691
+  }
+  st_out = st;
+  steps_out = my_steps;
+}
+
+__device__ __forceinline__ uint32_t step_cap(uint32_t factor, uint32_t len) {
+  unsigned long long c = (unsigned long long)factor * ((unsigned long long)len + 2ull);
+  return c > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)c;
+}
+
+__device__ __forceinline__ void add_steps(unsigned long long *counter, uint32_t mine) {
+  unsigned long long tot = mine;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) tot += __shfl_down(tot, o);
+  if (lane_id() == 0 && tot) atomicAdd(counter, tot);
+}
+
+// ---- one document per lane (no speculation) ----
+template <typename TRANS, bool IS_MATRIX>
+__global__ __launch_bounds__(WAVE) void k_walk_doc(TRANS tr, DtkWalkArgs A, uint32_t epsilon,
+                                                   uint32_t unknown, uint32_t identity) {
+  const uint32_t d = blockIdx.x * WAVE + threadIdx.x;
+  uint32_t steps = 0;
+  if (d < A.n_docs) {
+    const uint64_t off = A.doc_off[d];
+    const uint32_t len = (uint32_t)(A.doc_off[d + 1] - off);
+    EventSink sink;
+    sink.init(A.evA + off + d, A.evB + off + d, 0u, 0xFFFFFFFFu);
+    DtkLaneState init{0u, tr.start_state(), tr.start_aux(), 0u}, fin;
+    uint32_t st;
+    walk_lane<TRANS, IS_MATRIX, MODE_DOC>(tr, A.sym + off, len, init, 0u, sink, epsilon, unknown,
+                                          identity, step_cap(A.step_factor, len), fin, st, steps);
     sink.flush();
     A.status[d] = st | sink.st;
   }
-  // one atomic per wave for the lookup counter
-  unsigned long long tot = my_steps;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) tot += __shfl_down(tot, o);
-  if (lane_id() == 0 && tot) atomicAdd(A.steps, tot);
+  add_steps(A.steps, steps);
+}
+
+// ---- speculative chunk lanes ----
+//
+// Lane (d, k) covers the rewinds ("sync points": the moments the reference
+// rewinds its window, where the whole loop state is (position, state, three
+// flags)) that fall into [k*C, (k+1)*C) of document d.
+//   k_spec_start : lane k >= 1 walks from k*C - W in the start state and records
+//                  the first sync point at or after k*C  (the automaton
+//                  re-synchronises within a token or two).
+//   k_spec_plan  : per document, chains the records into windows.
+//   k_spec_walk  : each lane walks from its record to the next lane's record,
+//                  storing events inside its window only.
+//   k_spec_check : per document, verifies that every lane arrived exactly at its
+//                  successor's record (position, state, flags).  A document that
+//                  fails is repaired from the first bad lane on (host loop,
+//                  normally never entered) -- the result is exact either way.
+
+template <typename TRANS, bool IS_MATRIX>
+__global__ __launch_bounds__(WAVE) void k_spec_start(TRANS tr, DtkWalkArgs A, DtkSpecArgs S,
+                                                     uint32_t epsilon, uint32_t unknown,
+                                                     uint32_t identity) {
+  const uint32_t L = blockIdx.x * WAVE + threadIdx.x;
+  uint32_t steps = 0;
+  if (L < S.n_lanes) {
+    const uint32_t d = S.lane_doc[L];
+    const uint32_t k = L - S.chunk_off[d];
+    {
+      const uint64_t off = A.doc_off[d];
+      const uint32_t len = (uint32_t)(A.doc_off[d + 1] - off);
+      const uint16_t *__restrict__ s = A.sym + off;
+      DtkLaneState rec{0u, tr.start_state(), tr.start_aux(), 0u};
+      if (k > 0) {
+        const uint32_t kc = k * S.chunk;
+        uint32_t sp = kc > S.warm ? kc - S.warm : 0u;
+        if (sp > 0) {
+          while (sp < len && !(s[sp] & DTK_SYM_START)) sp++;
+          DtkLaneState init{sp, tr.start_state(), tr.start_aux(), 0u};
+          EventSink sink;
+          sink.init(nullptr, nullptr, 0u, 0u);
+          uint32_t st;
+          walk_lane<TRANS, IS_MATRIX, MODE_START>(tr, s, len, init, kc, sink, epsilon, unknown, identity,
+                                                  step_cap(A.step_factor, len), rec, st, steps);
+        }
+        // sp == 0: the walk from the true initial state; its first sync point at/after kc
+        else {
+          EventSink sink;
+          sink.init(nullptr, nullptr, 0u, 0u);
+          uint32_t st;
+          walk_lane<TRANS, IS_MATRIX, MODE_START>(tr, s, len, rec, kc, sink, epsilon, unknown, identity,
+                                                  step_cap(A.step_factor, len), rec, st, steps);
+        }
+      }
+      S.lane_start[L] = rec;
+    }
+  }
+  add_steps(A.steps, steps);
+}
+
+// One thread per document: enable the longest prefix of lanes whose records are
+// present and ordered, and give each its window end / stop position.
+__global__ __launch_bounds__(256) void k_spec_plan(DtkWalkArgs A, DtkSpecArgs S) {
+  const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= A.n_docs) return;
+  const uint32_t L0 = S.chunk_off[d], L1 = S.chunk_off[d + 1];
+  uint32_t first = L0;
+  if (S.redo_from) {
+    if (S.redo_from[d] == 0xFFFFFFFFu) return;
+    first = S.redo_from[d];
+  }
+  bool enabled = true;
+  for (uint32_t L = first; L < L1; L++) {
+    const uint32_t k = L - L0;
+    bool next_ok = false;
+    uint32_t next_p = 0;
+    if (enabled && L + 1 < L1) {
+      const DtkLaneState nx = S.lane_start[L + 1];
+      next_ok = nx.p != 0xFFFFFFFFu && nx.p >= S.lane_start[L].p;
+      next_p = nx.p;
+    }
+    DtkLanePlan pl;
+    if (!enabled) {
+      pl.stop = 0; pl.wend = 0; pl.mode = PLAN_OFF;
+    } else if (next_ok) {
+      pl.stop = next_p; pl.wend = next_p; pl.mode = PLAN_CHAINED;
+    } else {
+      // last enabled lane: stops at the first sync point behind its own chunk (or EOF)
+      pl.stop = (L + 1 < L1) ? (k + 1u) * S.chunk : 0xFFFFFFFFu;
+      pl.wend = 0xFFFFFFFFu;
+      pl.mode = PLAN_LAST;
+    }
+    S.lane_plan[L] = pl;
+    if (!next_ok) enabled = false;
+  }
+}
+
+template <typename TRANS, bool IS_MATRIX>
+__global__ __launch_bounds__(WAVE) void k_spec_walk(TRANS tr, DtkWalkArgs A, DtkSpecArgs S,
+                                                    uint32_t epsilon, uint32_t unknown,
+                                                    uint32_t identity) {
+  const uint32_t L = blockIdx.x * WAVE + threadIdx.x;
+  uint32_t steps = 0;
+  if (L < S.n_lanes) {
+    const uint32_t d = S.lane_doc[L];
+    const bool redo = S.redo_from != nullptr;
+    if (!redo || (S.redo_from[d] != 0xFFFFFFFFu && L >= S.redo_from[d])) {
+      const DtkLanePlan pl = S.lane_plan[L];
+      DtkLaneState fin{0xFFFFFFFFu, 0u, 0u, LANE_F_IDLE};
+      uint32_t st = 0;
+      if (pl.mode != PLAN_OFF) {
+        const uint64_t off = A.doc_off[d];
+        const uint32_t len = (uint32_t)(A.doc_off[d + 1] - off);
+        const DtkLaneState init = S.lane_start[L];
+        EventSink sink;
+        sink.init(A.evA + off + d, A.evB + off + d, init.p, pl.wend);
+        walk_lane<TRANS, IS_MATRIX, MODE_CHUNK>(tr, A.sym + off, len, init, pl.stop, sink, epsilon, unknown,
+                                                identity, step_cap(A.step_factor, len), fin, st, steps);
+        sink.flush();
+        st |= sink.st;
+        if (sink.dropped) fin.flags |= LANE_F_DROPPED;
+      }
+      S.lane_end[L] = fin;
+      S.lane_status[L] = st;
+    }
+  }
+  add_steps(A.steps, steps);
+}
+
+// One thread per document: did every lane arrive exactly at its successor's
+// record?  Writes status[d]; on failure records the first bad lane in
+// redo_from[d], replaces the successor's record by the true state and counts the
+// document in *n_bad.
+__global__ __launch_bounds__(256) void k_spec_check(DtkWalkArgs A, DtkSpecArgs S, uint32_t cmp_mask,
+                                                    uint32_t *redo_out, uint32_t *n_bad) {
+  const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= A.n_docs) return;
+  if (S.redo_from && S.redo_from[d] == 0xFFFFFFFFu) { return; }
+  const uint32_t L0 = S.chunk_off[d], L1 = S.chunk_off[d + 1];
+  uint32_t st = 0, bad = 0xFFFFFFFFu;
+  for (uint32_t L = L0; L < L1; L++) {
+    const DtkLanePlan pl = S.lane_plan[L];
+    const DtkLaneState en = S.lane_end[L];
+    if (pl.mode == PLAN_OFF) {
+      // only reachable when the chain ended legitimately (checked below at PLAN_LAST)
+      continue;
+    }
+    st |= S.lane_status[L];
+    if (pl.mode == PLAN_CHAINED) {
+      const DtkLaneState nx = S.lane_start[L + 1];
+      const bool same = en.p == nx.p && en.t == nx.t && ((en.flags ^ nx.flags) & cmp_mask) == 0 &&
+                        !(en.flags & LANE_F_DROPPED);
+      if (!same) { bad = L; break; }
+    } else {  // PLAN_LAST
+      if (L + 1 < L1) {
+        // fine only if this lane ran to EOF and no later lane found a sync point
+        bool fine = en.p == 0xFFFFFFFFu;
+        for (uint32_t M = L + 1; fine && M < L1; M++) fine = S.lane_start[M].p == 0xFFFFFFFFu;
+        if (!fine) { bad = L; break; }
+      } else if (en.p != 0xFFFFFFFFu) {
+        bad = L;  // the last lane of a document must finish the document
+        break;
+      }
+    }
+  }
+  if (bad == 0xFFFFFFFFu) {
+    A.status[d] = st;
+    redo_out[d] = 0xFFFFFFFFu;
+  } else {
+    // the lane `bad` started from a true state (all lanes before it checked out): where it
+    // really ended is the true record of its successor.  Redo from `bad` on.
+    DtkLaneState en = S.lane_end[bad];
+    en.flags &= (LANE_F_SENT | LANE_F_TEXT | LANE_F_OK);
+    if (en.p == 0xFFFFFFFFu) {  // ran to EOF: no later lane has a sync point
+      for (uint32_t M = bad + 1; M < L1; M++) S.lane_start[M].p = 0xFFFFFFFFu;
+    } else if (bad + 1 < L1) {
+      S.lane_start[bad + 1] = en;
+    }
+    redo_out[d] = bad;
+    atomicAdd(n_bad, 1u);
+  }
+}
+
+// Zeroes both event arrays of every document that is being repaired, from the
+// start position of its first redone lane to the end (one wave per document).
+__global__ __launch_bounds__(WAVE) void k_spec_clear(DtkWalkArgs A, DtkSpecArgs S) {
+  const uint32_t d = blockIdx.x;
+  if (d >= A.n_docs || S.redo_from[d] == 0xFFFFFFFFu) return;
+  const uint64_t off = A.doc_off[d];
+  const uint32_t len = (uint32_t)(A.doc_off[d + 1] - off);
+  const uint32_t from = S.lane_start[S.redo_from[d]].p;
+  uint8_t *a = A.evA + off + d, *b = A.evB + off + d;
+  for (uint32_t q = from + threadIdx.x; q <= len; q += WAVE) {
+    if (q > from) a[q] = 0;  // the closing byte at `from` belongs to the previous lane
+    b[q] = 0;
+  }
 }
 
 // ------------------------------------------------------------------ compact
@@ -436,7 +711,8 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
   if (d >= A.n_docs) return;
   const uint64_t off = A.doc_off[d];
   const uint32_t len = (uint32_t)(A.doc_off[d + 1] - off);
-  const uint8_t *__restrict__ ev = A.events + off + d;
+  const uint8_t *__restrict__ evA = A.evA + off + d;
+  const uint8_t *__restrict__ evB = A.evB + off + d;
   const uint16_t *__restrict__ sym = A.sym + off;
   const uint8_t *__restrict__ txt = A.text + off;
   const bool nl_rule = (A.flags & 16u) != 0;  // NEWLINE_AFTER_EOT
@@ -469,7 +745,7 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
   for (uint32_t base = 0; base <= len; base += WAVE) {
     const uint32_t P = base + lane;
     uint32_t f = 0, rs = 0, tb = 0;
-    if (P <= len) f = ev[P];
+    if (P <= len) f = (uint32_t)evA[P] | (uint32_t)evB[P];
     if (P < len) {
       rs = sym[P] >> 15;
       tb = txt[P];
@@ -693,26 +969,66 @@ extern "C" int dtk_launch_symbolize(const uint8_t *text, const uint64_t *doc_off
   return (int)hipGetLastError();
 }
 
+template <typename F>
+static int with_trans(const DtkTableDev *tab, F &&f) {
+  if (tab->kind == DTK_KIND_MATRIX) {
+    if (tab->entry_bytes == 2) {
+      MatrixTrans<uint16_t> tr{(const uint16_t *)tab->tab, tab->stride, tab->n_eps, tab->start};
+      f(tr, std::true_type{});
+    } else {
+      MatrixTrans<uint32_t> tr{(const uint32_t *)tab->tab, tab->stride, tab->n_eps, tab->start};
+      f(tr, std::true_type{});
+    }
+  } else {
+    DaTrans tr{(const uint2 *)tab->tab, tab->da_len, tab->da_size, tab->da_base1};
+    f(tr, std::false_type{});
+  }
+  return (int)hipGetLastError();
+}
+
 extern "C" int dtk_launch_walk(const DtkTableDev *tab, const DtkWalkArgs *args, void *stream) {
   if (args->n_docs == 0) return 0;
   const uint32_t blocks = (args->n_docs + WAVE - 1) / WAVE;
   hipStream_t s = (hipStream_t)stream;
-  if (tab->kind == DTK_KIND_MATRIX) {
-    if (tab->entry_bytes == 2) {
-      MatrixTrans<uint16_t> tr{(const uint16_t *)tab->tab, tab->stride, tab->n_eps, tab->start};
-      hipLaunchKernelGGL((k_walk<MatrixTrans<uint16_t>, true>), dim3(blocks), dim3(WAVE), 0, s, tr, *args,
-                         tab->epsilon, tab->unknown, tab->identity);
-    } else {
-      MatrixTrans<uint32_t> tr{(const uint32_t *)tab->tab, tab->stride, tab->n_eps, tab->start};
-      hipLaunchKernelGGL((k_walk<MatrixTrans<uint32_t>, true>), dim3(blocks), dim3(WAVE), 0, s, tr, *args,
-                         tab->epsilon, tab->unknown, tab->identity);
-    }
-  } else {
-    DaTrans tr{(const uint2 *)tab->tab, tab->da_len, tab->da_size, tab->da_base1};
-    hipLaunchKernelGGL((k_walk<DaTrans, false>), dim3(blocks), dim3(WAVE), 0, s, tr, *args, tab->epsilon,
-                       tab->unknown, tab->identity);
+  return with_trans(tab, [&](auto tr, auto is_matrix) {
+    using TR = decltype(tr);
+    hipLaunchKernelGGL((k_walk_doc<TR, decltype(is_matrix)::value>), dim3(blocks), dim3(WAVE), 0, s, tr, *args,
+                       tab->epsilon, tab->unknown, tab->identity);
+  });
+}
+
+// stage: 0 start records, 1 plan, 2 walk, 3 check (redo_out / n_bad), 4 clear (repair only)
+extern "C" int dtk_launch_spec(const DtkTableDev *tab, const DtkWalkArgs *args, const DtkSpecArgs *spec,
+                               int stage, uint32_t cmp_mask, uint32_t *redo_out, uint32_t *n_bad,
+                               void *stream) {
+  if (args->n_docs == 0 || spec->n_lanes == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const uint32_t lane_blocks = (spec->n_lanes + WAVE - 1) / WAVE;
+  const uint32_t doc_blocks = (args->n_docs + 255) / 256;
+  switch (stage) {
+    case 0:
+      return with_trans(tab, [&](auto tr, auto is_matrix) {
+        using TR = decltype(tr);
+        hipLaunchKernelGGL((k_spec_start<TR, decltype(is_matrix)::value>), dim3(lane_blocks), dim3(WAVE), 0, s,
+                           tr, *args, *spec, tab->epsilon, tab->unknown, tab->identity);
+      });
+    case 1:
+      hipLaunchKernelGGL(k_spec_plan, dim3(doc_blocks), dim3(256), 0, s, *args, *spec);
+      return (int)hipGetLastError();
+    case 2:
+      return with_trans(tab, [&](auto tr, auto is_matrix) {
+        using TR = decltype(tr);
+        hipLaunchKernelGGL((k_spec_walk<TR, decltype(is_matrix)::value>), dim3(lane_blocks), dim3(WAVE), 0, s,
+                           tr, *args, *spec, tab->epsilon, tab->unknown, tab->identity);
+      });
+    case 3:
+      hipLaunchKernelGGL(k_spec_check, dim3(doc_blocks), dim3(256), 0, s, *args, *spec, cmp_mask, redo_out, n_bad);
+      return (int)hipGetLastError();
+    case 4:
+      hipLaunchKernelGGL(k_spec_clear, dim3(args->n_docs), dim3(WAVE), 0, s, *args, *spec);
+      return (int)hipGetLastError();
   }
-  return (int)hipGetLastError();
+  return -1;
 }
 
 extern "C" int dtk_launch_compact(const DtkCompactArgs *args, int pass, void *stream) {

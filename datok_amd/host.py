@@ -295,6 +295,12 @@ class Batch:
     def sync(self):
         check(lib().dtk_batch_sync(self._h), "dtk_batch_sync")
 
+    AUTO_CHUNK = 0xFFFFFFFF
+
+    def set_chunking(self, chunk_bytes=AUTO_CHUNK, warm_bytes=64):
+        """0: one lane per document; otherwise speculative chunk lanes (exact either way)."""
+        check(lib().dtk_batch_set_chunking(self._h, int(chunk_bytes), int(warm_bytes)), "dtk_batch_set_chunking")
+
     def set_profiling(self, enable=True):
         check(lib().dtk_batch_set_profiling(self._h, int(bool(enable))), "dtk_batch_set_profiling")
 
@@ -339,6 +345,6 @@ class Batch:
         r.text_tok_end = arr(v.text_tok_end, t["n_texts"], np.uint32)
         r.text_sent_end = arr(v.text_sent_end, t["n_texts"], np.uint32)
         r.status = arr(v.status, nd, np.uint32)
-        r.events = arr(v.events, self.total + nd, np.uint8)
+        r.events = arr(v.events, self.total + nd, np.uint8) | arr(v.events_open, self.total + nd, np.uint8)
         r.doc_off = self._doc_off
         return r

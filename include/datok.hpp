@@ -107,12 +107,13 @@ inline int count_runes(const uint8_t *p, size_t n) {
 // The int arguments follow the reference: the matrix passes buffc everywhere
 // (matrix.go:575,597,600,684,691), the double array passes 0 except for the
 // SentenceEnd fired by EOT (datok.go:1015,1023,1026,1119,1127).
-inline void replay(bool is_matrix, const uint8_t *text, size_t n, const uint8_t *ev, TokenWriter &w) {
+inline void replay(bool is_matrix, const uint8_t *text, size_t n, const uint8_t *ev_close,
+                   const uint8_t *ev_open, TokenWriter &w) {
   size_t B = 0;      // byte position of the window start (last rewind)
   size_t start = 0;  // byte position of the pending token start
   std::vector<rune> buf;
   for (size_t p = 0; p <= n; p++) {
-    const uint8_t e = ev[p];
+    const uint8_t e = (uint8_t)(ev_close[p] | ev_open[p]);
     if (!e) continue;
     auto buffc = [&]() { return count_runes(text + B, p - B); };
     if (e & DTK_EV_S_EOT) w.SentenceEnd(buffc());
@@ -267,7 +268,7 @@ class GpuTokenizer final : public Tokenizer {
               dtk_batch_result_host(b, &v) == DTK_OK;
     if (ok) {
       last_status_ = v.status[0];
-      detail::replay(Type() == "MATOK", text, n, v.events, w);
+      detail::replay(Type() == "MATOK", text, n, v.events, v.events_open, w);
     }
     dtk_batch_free(b);
     return ok;

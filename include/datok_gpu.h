@@ -108,6 +108,14 @@ int dtk_batch_set_input(dtk_batch *b, const uint8_t *text, const uint64_t *doc_o
 int dtk_batch_set_input_device(dtk_batch *b, const void *d_text, const void *d_doc_off,
                                uint32_t n_docs, uint64_t total_bytes);
 
+/* Walk strategy.  chunk_bytes = 0: one lane per document.  Otherwise documents are
+ * cut into chunks of chunk_bytes; every chunk is walked by its own lane from a
+ * speculative start found warm_bytes earlier, and a check pass proves that each
+ * lane arrived exactly where its successor started (mismatches are repaired, the
+ * result is always exact).  0xFFFFFFFF (the default) picks the chunk size from
+ * the batch size.  warm_bytes defaults to 64. */
+int dtk_batch_set_chunking(dtk_batch *b, uint32_t chunk_bytes, uint32_t warm_bytes);
+
 /* Launches the whole path on the batch's stream (asynchronous):
  * symbolise -> walk -> count -> scan -> compact.  flags: DTK_NEWLINE_AFTER_EOT
  * is the only bit that changes the numbers (token_writer.go:66-68). */
@@ -131,7 +139,10 @@ typedef struct {
   uint64_t n_sent;        /* ints in the flat sentence list (token_writer.go:78,108) */
   uint64_t n_texts;       /* TextEnd calls */
   uint64_t n_flagged;     /* documents with status != 0 */
-  uint64_t walk_steps;    /* table lookups performed by the walk kernel */
+  uint64_t walk_steps;    /* table lookups performed by the walk kernels (warm-ups included) */
+  uint32_t n_lanes;       /* lanes the walk ran on */
+  uint32_t chunk_bytes;   /* chunk size used (0: one lane per document) */
+  uint32_t repair_rounds; /* speculation repair rounds (normally 0) */
 } dtk_totals;
 int dtk_batch_totals(dtk_batch *b, dtk_totals *out);
 
@@ -158,8 +169,11 @@ typedef struct {
   const uint32_t *text_tok_end, *text_sent_end;
   const uint32_t *status;
   /* raw walk output, for replay into TokenWriter closures: one byte per byte
-   * position of every document plus one (index doc_off[d] + d + p) */
+   * position of every document plus one (index doc_off[d] + d + p).  The calls
+   * fired by a window rewind (S_EOT, E_EOT, TOK_END) are in `events`, all
+   * others in `events_open`; OR the two bytes. */
   const uint8_t *events;
+  const uint8_t *events_open;
 } dtk_result_view;
 int dtk_batch_result_device(dtk_batch *b, dtk_result_view *out);
 /* Copies the arrays to host memory owned by the batch (valid until the next

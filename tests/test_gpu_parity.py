@@ -29,9 +29,12 @@ def gpu():
     return get
 
 
-def run_batch(tok, text, doc_off, flags=0):
+def run_batch(tok, text, doc_off, flags=0, chunk=None, warm=64):
+    """chunk=None: library default (automatic chunking); 0: one lane per document."""
     import datok_amd
     with datok_amd.Batch(max(len(text), 1), len(doc_off) - 1) as b:
+        if chunk is not None:
+            b.set_chunking(chunk, warm)
         b.set_input(text, doc_off)
         b.run(tok, flags)
         return b.result(), b.totals()
@@ -103,12 +106,15 @@ def test_config1_simpletok_1k(gpu, oracle_models):
     assert (out, st) == oracle_models("simpletok.matok").transduce(text.tobytes())
 
 
-def test_config2_german_4096x4096_full(gpu, oracle_models):
-    """The bench workload itself, every document, every offset."""
+@pytest.mark.parametrize("chunk", [None, 0])
+def test_config2_german_4096x4096_full(gpu, oracle_models, chunk):
+    """The bench workload itself, every document, every offset; default (speculative chunk
+    lanes) and one-lane-per-document walk."""
     from datok_amd import corpus
     text, off = corpus.german_docs(4096, 4096, seed=2)
-    res, tot = run_batch(gpu("tokenizer_de.matok"), text, off)
+    res, tot = run_batch(gpu("tokenizer_de.matok"), text, off, chunk=chunk)
     assert tot["n_flagged"] == 0 and tot["n_texts"] == 4096
+    assert (tot["n_lanes"] > 4096) == (chunk is None)
     n = assert_batch_equals_oracle(oracle_models("tokenizer_de.matok"), res, text, off)
     assert n == 4096
     counts = oracle_models("tokenizer_de.matok").count_batch(text, off, 4)
@@ -155,13 +161,15 @@ def _edge_docs():
 
 @pytest.mark.parametrize("model", ["tokenizer_de.matok", "tokenizer_en.matok", "clitic_test.matok",
                                    "simpletok.matok", "simpletok.datok", "tokenizer_de.datok"])
-@pytest.mark.parametrize("flags", [0, NEWLINE_AFTER_EOT])
-def test_edge_documents(gpu, oracle_models, model, flags):
-    """Empty / ragged / EOT / invalid UTF-8 / window-overflow documents in one batch."""
+@pytest.mark.parametrize("flags,chunk,warm", [(0, 0, 64), (NEWLINE_AFTER_EOT, 0, 64), (0, 16, 64),
+                                              (NEWLINE_AFTER_EOT, 32, 8), (0, 64, 0)])
+def test_edge_documents(gpu, oracle_models, model, flags, chunk, warm):
+    """Empty / ragged / EOT / invalid UTF-8 / window-overflow documents in one batch, walked
+    one lane per document and as speculative chunks (small warm-ups force repair rounds)."""
     from datok_amd import corpus, ST_IRREGULAR
     docs = _edge_docs()
     text, off = corpus.concat_docs(docs)
-    res, tot = run_batch(gpu(model), text, off, flags)
+    res, tot = run_batch(gpu(model), text, off, flags, chunk=chunk, warm=warm)
     # the double array may revisit an EOT (datok.go:1019-1030 keeps its window): such
     # documents are flagged IRREGULAR and excluded, everything else must be bit exact
     irregular = [d for d in range(len(docs)) if res.status[d] & ST_IRREGULAR]
@@ -170,6 +178,33 @@ def test_edge_documents(gpu, oracle_models, model, flags):
     keep = [d for d in range(len(docs)) if d not in set(irregular)]
     n = assert_batch_equals_oracle(oracle_models(model), res, text, off, flags, docs=keep)
     assert n > 200
+
+
+@pytest.mark.parametrize("model", ["tokenizer_de.matok", "tokenizer_de.datok", "tokenizer_en.matok"])
+@pytest.mark.parametrize("chunk,warm", [(64, 64), (256, 64), (1024, 32), (128, 0), (48, 4), (4096, 64)])
+def test_speculative_chunks_are_exact(gpu, oracle_models, model, chunk, warm):
+    """Chunk lanes + check/repair must reproduce the sequential walk bit for bit, also when the
+    warm-up is too short to re-synchronise (warm 0 / 4: about a third of the lanes mispredict)."""
+    from datok_amd import corpus
+    if model.endswith("en.matok"):
+        text, off = corpus.english_zipf_docs(512, seed=4, max_bytes=16384)
+    else:
+        text, off = corpus.german_docs(384, 4096, seed=9)
+    res, tot = run_batch(gpu(model), text, off, chunk=chunk, warm=warm)
+    assert tot["n_flagged"] == 0 and tot["chunk_bytes"] == chunk
+    if warm == 0:
+        assert tot["repair_rounds"] > 0
+    assert_batch_equals_oracle(oracle_models(model), res, text, off)
+
+
+def test_long_single_stream_is_chunked(gpu, oracle_models):
+    """One 2 MiB document (the reference's one-reader use): thousands of lanes, same offsets."""
+    from datok_amd import corpus
+    text, _ = corpus.german_docs(512, 4096, seed=21)
+    off = np.array([0, len(text)], dtype=np.uint64)
+    res, tot = run_batch(gpu("tokenizer_de.matok"), text, off)
+    assert tot["n_lanes"] > 1000 and tot["n_flagged"] == 0
+    assert_batch_equals_oracle(oracle_models("tokenizer_de.matok"), res, text, off)
 
 
 def test_rendered_output_all_flag_combinations(gpu, oracle_models):
