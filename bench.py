@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--docs", type=int, default=4096, help="documents per GPU")
     ap.add_argument("--doc-bytes", type=int, default=4096)
     ap.add_argument("--model", default=MODEL)
+    ap.add_argument("--chunk", type=int, default=-1, help="-1 automatic, 0 one lane per document, else bytes")
+    ap.add_argument("--warm", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--parity-docs", type=int, default=256, help="documents checked against the oracle before timing")
@@ -81,6 +83,7 @@ def main():
     torch.cuda.synchronize()
 
     batch = datok_amd.Batch(total, args.docs)
+    batch.set_chunking(datok_amd.Batch.AUTO_CHUNK if args.chunk < 0 else args.chunk, args.warm)
     batch.set_input_device(t_text.data_ptr(), t_off.data_ptr(), args.docs, total,
                            keep=(t_text, t_off), doc_off_host=doc_off)
     stream = torch.cuda.ExternalStream(batch.stream, device=dev)
@@ -216,6 +219,8 @@ def main():
                          "Glookups_per_s": round(tot["walk_steps"] / walk_s / 1e9, 3)},
             "stages_ms": {k: round(v, 4) for k, v in stage_avg.items()},
             "tokens_per_launch": int(tot["n_tokens"]),
+            "walk": {"lanes": int(tot["n_lanes"]), "chunk_bytes": int(tot["chunk_bytes"]), "warm_bytes": args.warm,
+                     "repair_rounds": int(tot["repair_rounds"])},
             "gather_ms": None if gather_ms is None else round(gather_ms, 3),
             "cpu_baseline": cpu,
         }

@@ -417,6 +417,7 @@ struct dtk_batch {
   // intermediates
   uint16_t *d_sym = nullptr;
   uint8_t *d_evA = nullptr, *d_evB = nullptr;  // closing / opening event bytes
+  uint32_t *d_tlen = nullptr;                  // token lengths at their end positions
   uint32_t *d_status = nullptr;
   // speculative chunk lanes
   std::vector<uint64_t> h_doc_off;   // host copy of the document offsets (lane planning)
@@ -500,6 +501,7 @@ extern "C" int dtk_batch_create(uint64_t max_bytes, uint32_t max_docs, dtk_batch
   B_TRY(hipMalloc((void **)&b->d_sym, (max_bytes + pad) * 2));
   B_TRY(hipMalloc((void **)&b->d_evA, max_bytes + max_docs + pad));
   B_TRY(hipMalloc((void **)&b->d_evB, max_bytes + max_docs + pad));
+  B_TRY(hipMalloc((void **)&b->d_tlen, (max_bytes + max_docs + pad) * 4));
   B_TRY(hipMalloc((void **)&b->d_redo, (uint64_t)max_docs * 4));
   B_TRY(hipMalloc((void **)&b->d_chunk_off, ((uint64_t)max_docs + 1) * 4));
   B_TRY(hipMalloc((void **)&b->d_status, (uint64_t)max_docs * 4));
@@ -520,7 +522,7 @@ extern "C" int dtk_batch_create(uint64_t max_bytes, uint32_t max_docs, dtk_batch
 extern "C" void dtk_batch_free(dtk_batch *b) {
   if (!b) return;
   if (b->stream) (void)hipStreamSynchronize(b->stream);
-  void *ptrs[] = {b->d_text_own, b->d_off_own, b->d_sym, b->d_evA, b->d_evB, b->d_redo, b->d_chunk_off,
+  void *ptrs[] = {b->d_text_own, b->d_off_own, b->d_sym, b->d_evA, b->d_evB, b->d_tlen, b->d_redo, b->d_chunk_off,
                   b->d_lane_doc, b->d_lane_status, b->d_lane_start, b->d_lane_end, b->d_lane_plan,
                   b->d_status, b->d_tok_off,
                   b->d_sent_off, b->d_text_off, b->d_totals, b->d_rstart, b->d_rend, b->d_sent,
@@ -596,7 +598,7 @@ static int plan_lanes(dtk_batch *b) {
   if (C == 0xFFFFFFFFu) {
     // enough lanes to give every SIMD of the chip a few waves, but chunks no shorter than
     // a few warm-ups: 256 CUs x 4 SIMDs x 64 lanes = 65536 lanes per "wave per SIMD"
-    const uint64_t want_lanes = 4ull * 65536ull;
+    const uint64_t want_lanes = 2ull * 65536ull;  // measured best on 16 MiB: C = 128
     uint64_t c = b->total / want_lanes;
     uint32_t p2 = 128;
     while (p2 < c && p2 < 4096) p2 <<= 1;
@@ -643,7 +645,7 @@ static int plan_lanes(dtk_batch *b) {
 static DtkWalkArgs walk_args(dtk_batch *b) {
   DtkWalkArgs w{};
   w.sym = b->d_sym; w.doc_off = b->d_off; w.n_docs = b->n_docs;
-  w.evA = b->d_evA; w.evB = b->d_evB; w.status = b->d_status;
+  w.evA = b->d_evA; w.evB = b->d_evB; w.tlen = b->d_tlen; w.status = b->d_status;
   w.steps = (unsigned long long *)(b->d_totals + 4);
   w.step_factor = 2048;  // look-ahead is bounded by the 1024-rune window (matrix.go:365)
   return w;
@@ -708,7 +710,7 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
   STAGE(3);
   DtkCompactArgs c{};
   c.text = b->d_text; c.sym = b->d_sym; c.doc_off = b->d_off; c.n_docs = b->n_docs;
-  c.evA = b->d_evA; c.evB = b->d_evB; c.status = b->d_status;
+  c.evA = b->d_evA; c.evB = b->d_evB; c.tlen = b->d_tlen; c.status = b->d_status;
   c.flags = flags & DTK_NEWLINE_AFTER_EOT; c.kind = m->kind;
   c.tok_off = b->d_tok_off; c.sent_off = b->d_sent_off; c.text_off = b->d_text_off;
   c.totals = b->d_totals;

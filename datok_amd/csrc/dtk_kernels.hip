@@ -234,60 +234,72 @@ struct DaTrans {
   }
 };
 
-// Event bytes are written lane-privately.  "Closing" calls (S_EOT, E_EOT,
-// TOK_END: what a rewind of the window fires) and "opening" calls (everything
-// fired after it) live in two byte arrays, so that the lane whose walk ends with
-// a rewind at position q and the lane that starts from q never store to the
-// same byte.  Cursor positions of successive events never decrease for the
-// matrix walk, so one pending byte per array is enough; the double array can
-// revisit a position (no rewind at EOT, datok.go:1019-1030), which takes the
-// read-modify-write path.  A lane only stores inside its window
+// Events are stored lane-privately, one byte per cursor position, in two arrays:
+// "closing" calls (S_EOT, E_EOT, TOK_END: what a rewind of the window fires) and
+// "opening" calls (the SentenceEnd / TextEnd fired afterwards), so that the lane
+// whose walk ends with a rewind at position q and the lane that starts from q
+// never store to the same byte.  A token is recorded at its END position only:
+// the closing byte plus (byte length | rune length << 16) in a third array, from
+// which the compaction derives its start.  Cursor positions of successive events
+// never decrease for the matrix walk, and no byte is written twice except in the
+// cases tracked here in registers (a second epsilon SentenceEnd at one cursor;
+// for the double array a token that ends where an EOT fired, datok.go:1019-1030
+// keeps its window).  A lane only stores inside its window
 //   opening: lo <= pos < hi      closing: lo < pos <= hi
 // (whole document: lo = 0, hi = 0xFFFFFFFF); an event outside is dropped and
-// remembered, the validator then knows the lane left its window.
-#define EV_CLOSING (EV_S_EOT | EV_E_EOT | EV_TOK_END)
-
+// remembered, the check pass then knows the lane left its window.
 struct EventSink {
-  uint8_t *evA, *evB;          // closing / opening, index = position in the document
-  uint32_t pA, fA, pB, fB;     // pending position / byte per array
-  uint32_t hiwA, hiwB;         // highest position stored so far (read-modify-write path)
-  uint32_t lo, hi;             // window
+  uint8_t *evA, *evB;  // closing / opening, index = position in the document
+  uint32_t *tlen;      // token lengths, index = end position
+  uint32_t lo, hi;     // window
+  uint32_t last_s_p, s_bits;      // position / byte of the last opening SentenceEnd
+  uint32_t last_eot_p, eot_bits;  // position / byte of the last EOT pair (double array merge)
   uint32_t st;
   bool dropped;
-  __device__ __forceinline__ void init(uint8_t *a, uint8_t *b, uint32_t wlo, uint32_t whi) {
-    evA = a; evB = b; pA = pB = 0xFFFFFFFFu; fA = fB = 0; hiwA = hiwB = 0; lo = wlo; hi = whi; st = 0;
-    dropped = false;
+  __device__ __forceinline__ void init(uint8_t *a, uint8_t *b, uint32_t *tl, uint32_t wlo, uint32_t whi) {
+    evA = a; evB = b; tlen = tl; lo = wlo; hi = whi;
+    last_s_p = last_eot_p = 0xFFFFFFFFu; s_bits = eot_bits = 0; st = 0; dropped = false;
   }
-  __device__ __forceinline__ void flush() {
-    if (pA != 0xFFFFFFFFu && fA) evA[pA] = (uint8_t)fA;
-    if (pB != 0xFFFFFFFFu && fB) evB[pB] = (uint8_t)fB;
+  __device__ __forceinline__ bool in_closing(uint32_t p) const { return p > lo && p <= hi; }
+  __device__ __forceinline__ bool in_opening(uint32_t p) const { return p >= lo && p < hi; }
+
+  // Token(bufft, buffer[:buffc]) -- matrix.go:528,569,675
+  template <bool IS_MATRIX>
+  __device__ __forceinline__ void token(uint32_t tp, uint32_t p, uint32_t rl) {
+    if (!in_closing(p)) { dropped = true; return; }
+    uint32_t bits = EV_TOK_END;
+    if (!IS_MATRIX && p == last_eot_p) bits |= eot_bits;
+    evA[p] = (uint8_t)bits;
+    const uint32_t bl = p - tp;
+    tlen[p] = (bl > 0xFFFFu ? 0xFFFFu : bl) | ((rl > 0xFFFFu ? 0xFFFFu : rl) << 16);
   }
-  template <bool MONOTONIC>
-  __device__ __forceinline__ void emit(uint32_t p, uint32_t bit) {
-    const bool closing = (bit & EV_CLOSING) != 0;
-    if (closing ? !(p > lo && p <= hi) : !(p >= lo && p < hi)) { dropped = true; return; }
-    uint32_t &cp = closing ? pA : pB;
-    uint32_t &cf = closing ? fA : fB;
-    uint32_t &hw = closing ? hiwA : hiwB;
-    uint8_t *ev = closing ? evA : evB;
-    if (p != cp) {
-      if (cp != 0xFFFFFFFFu && cf) {
-        ev[cp] = (uint8_t)cf;
-        if (cp > hw) hw = cp;
-      }
-      cf = 0;
-      if (!MONOTONIC) {
-        if (cp != 0xFFFFFFFFu && p <= hw) cf = ev[p];
-      }
-      cp = p;
+  // SentenceEnd? + TextEnd fired by an EOT rune -- matrix.go:593-600
+  template <bool IS_MATRIX>
+  __device__ __forceinline__ void eot(uint32_t p, bool with_sentence) {
+    if (!in_closing(p)) { dropped = true; return; }
+    if (!IS_MATRIX && p == last_eot_p) st |= ST_IRREGULAR;  // the same EOT consumed twice
+    const uint32_t bits = EV_E_EOT | (with_sentence ? EV_S_EOT : 0u);
+    if (!IS_MATRIX) { last_eot_p = p; eot_bits = bits; }
+    evA[p] = (uint8_t)bits;
+  }
+  // SentenceEnd from an epsilon arc on an empty token -- matrix.go:574-575
+  __device__ __forceinline__ void sentence(uint32_t p) {
+    if (!in_opening(p)) { dropped = true; return; }
+    if (p == last_s_p) {
+      if (s_bits & EV_S_EPS2) st |= ST_IRREGULAR;
+      s_bits |= EV_S_EPS2;
+    } else {
+      last_s_p = p;
+      s_bits = EV_S_EPS;
     }
-    if (bit == EV_S_EPS && (cf & EV_S_EPS)) {
-      if (cf & EV_S_EPS2) st |= ST_IRREGULAR;
-      bit = EV_S_EPS2;
-    } else if ((bit & (EV_E_EOT | EV_S_EOT | EV_TOK_END | EV_TOK_START)) && (cf & bit)) {
-      st |= ST_IRREGULAR;
-    }
-    cf |= bit;
+    evB[p] = (uint8_t)s_bits;
+  }
+  // final SentenceEnd / TextEnd -- matrix.go:683-691
+  __device__ __forceinline__ void tail(uint32_t p, bool sentence_end, bool text_end) {
+    const uint32_t bits = (sentence_end ? 0u : EV_S_EOF) | (text_end ? 0u : EV_E_EOF);
+    if (!bits) return;
+    if (!in_opening(p)) { dropped = true; return; }
+    evB[p] = (uint8_t)(bits | (p == last_s_p ? s_bits : 0u));
   }
 };
 
@@ -298,36 +310,59 @@ enum { MODE_DOC = 0,    // whole document from the initial state, all events
                         // rewind at/after stop_pos (or run the EOF tail)
 };
 
+// Runes in [from, to): only needed when a window may have outgrown the
+// reference's 1024-rune buffer (matrix.go:365), i.e. when it spans > 1024 bytes.
+__device__ __noinline__ uint32_t count_runes(const uint16_t *__restrict__ s, uint32_t from, uint32_t to) {
+  uint32_t n = 0;
+  for (uint32_t i = from; i < to; i++) n += (s[i] >> 15);
+  return n;
+}
+
 // The walk of matrix.go:348-698 / datok.go:781-1135 for one lane.
 // Returns through `fin`: p == 0xFFFFFFFF means "ran to EOF" (MODE_START: no
 // rewind found; otherwise: tail done).
+//
+// The reference's rune window is not materialised: p / tp / bs / hi are byte
+// positions of buffer[buffc] / buffer[bufft] / buffer[0] / buffer[buffi], and the
+// symbol stream (4 entries per 8-byte load, the next group always in flight)
+// replaces the rune -> symbol lookups of matrix.go:421-435.
 template <typename TRANS, bool IS_MATRIX, int MODE>
-__device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__restrict__ s, uint32_t len,
-                                          DtkLaneState init, uint32_t stop_pos, EventSink &sink,
-                                          uint32_t epsilon, uint32_t unknown, uint32_t identity,
-                                          uint32_t cap, DtkLaneState &fin, uint32_t &st_out,
-                                          uint32_t &steps_out) {
-  // loop state, named after matrix.go:349-381
+__device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__restrict__ sym_base,
+                                          uint64_t off, uint32_t len, DtkLaneState init, uint32_t stop_pos,
+                                          EventSink &sink, uint32_t epsilon, uint32_t unknown,
+                                          uint32_t identity, uint32_t cap, DtkLaneState &fin,
+                                          uint32_t &st_out, uint32_t &steps_out) {
+  // symbol stream addressed in aligned groups of 4 entries
+  const uint32_t o3 = (uint32_t)(off & 3u);
+  const uint64_t *__restrict__ sq = reinterpret_cast<const uint64_t *>(sym_base + (off - o3));
+  const uint16_t *__restrict__ s = sym_base + off;
+
   uint32_t a = 0, t0 = 0, aux0 = 0;
-  uint32_t t = init.t, aux = init.aux;  // matrix.go:351 `t := uint32(1)` for MODE_DOC
+  uint32_t t = init.t, aux = init.aux;  // matrix.go:351 `t := uint32(1)`
   const uint32_t t_start = tr.start_state(), aux_start = tr.start_aux();
   bool ok = (init.flags & LANE_F_OK) != 0;  // sticky `ok` of matrix.go:352 / datok.go:785
-  uint32_t eps_t = 0, eps_aux = 0, eps_p = 0, eps_r = 0;  // epsilonState / epsilonOffset
+  uint32_t eps_t = 0, eps_aux = 0, eps_p = 0, eps_rl = 0;  // epsilonState / epsilonOffset
   bool sentence_end = (init.flags & LANE_F_SENT) != 0, text_end = (init.flags & LANE_F_TEXT) != 0;
-  uint32_t p = init.p;   // byte position of buffer[buffc]
-  uint32_t tp = init.p;  // byte position of buffer[bufft]
-  uint32_t hi = init.p;  // byte position behind buffer[buffi-1]: read high-water mark
-  uint32_t rc = 0;       // buffc (runes since the last rewind)
-  uint32_t ri = 0;       // buffi
+  uint32_t p = init.p;   // buffer[buffc]
+  uint32_t tp = init.p;  // buffer[bufft]
+  uint32_t bs = init.p;  // buffer[0]: position of the last rewind
+  uint32_t hi = init.p;  // behind buffer[buffi-1]: read high-water mark
+  uint32_t rl = 0;       // runes in [tp, p)
   uint32_t w = 1;        // width of the rune at p
-  uint32_t e = 0, e_pos = 0xFFFFFFFFu, e_next = 0;  // symbol entry of position e_pos; prefetched successor
   bool eot = false, newchar = true;
   uint32_t st = 0, my_steps = 0;
   fin.p = 0xFFFFFFFFu; fin.t = 0; fin.aux = 0; fin.flags = 0;
   bool stopped = false;
 
-#define SYNC_POINT()                                                                          \
+  uint32_t grp = 0xFFFFFFFEu;    // group index held in q_cur; q_next holds grp + 1 (none yet)
+  uint64_t q_cur = 0, q_next = 0;
+
+  // window rewind: matrix.go:537-543 / 608-627.  The 1024-rune limit of the
+  // reference is checked here, where the window was at its longest.
+#define REWIND()                                                                              \
   do {                                                                                        \
+    if (hi - bs > DTK_WINDOW && count_runes(s, bs, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW; \
+    tp = p; bs = p; rl = 0; eps_t = 0;                                                        \
     if (MODE != MODE_DOC && p >= stop_pos) {                                                  \
       fin.p = p; fin.t = t; fin.aux = aux;                                                    \
       fin.flags = (sentence_end ? LANE_F_SENT : 0u) | (text_end ? LANE_F_TEXT : 0u) |         \
@@ -348,27 +383,27 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
         } else if (eps_t != 0) {
           t0 = eps_t; aux0 = eps_aux;
           eps_t = 0;
-          p = eps_p; rc = eps_r;
+          p = eps_p; rl = eps_rl;
         } else {
           break;
         }
       } else {
-        if (e_pos != p) { e = s[p]; e_pos = p; }  // only after a backtrack / restart
+        const uint32_t i = p + o3, g = i >> 2;
+        if (g != grp) {
+          if (g == grp + 1u) q_cur = q_next; else q_cur = sq[g];   // else: after a backtrack / at start
+          q_next = sq[g + 1u];                                    // in flight for the next ~4 runes
+          grp = g;
+        }
+        const uint32_t e = (uint32_t)(q_cur >> ((i & 3u) * 16u)) & 0xFFFFu;
         a = e & DTK_SYM_MASK;
         w = ((e >> DTK_SYM_W_SHIFT) & 3u) + 1u;
         const uint32_t cls = (e >> DTK_SYM_CLS_SHIFT) & 3u;
-        // the successor is fetched while the transition load is in flight
-        e_next = (p + w < len) ? (uint32_t)s[p + w] : 0u;
-        if (p >= hi) {  // a rune not yet in the window (matrix.go:388-408)
-          if (ri >= DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
-          ri++;
-          hi = p + w;
-        }
+        hi = max(hi, p + w);             // matrix.go:388-408: runes enter the window once
         eot = cls == 1u;                 // matrix.go:422
         if (cls >= 2u) ok = cls == 2u;   // matrix.go:427: only runes >= 256 write `ok`
         t0 = t; aux0 = aux;              // matrix.go:437
         if (tr.has_eps(t0, aux0)) {      // matrix.go:442-454
-          eps_t = t0; eps_aux = aux0; eps_p = p; eps_r = rc;
+          eps_t = t0; eps_aux = aux0; eps_p = p; eps_rl = rl;
         }
       }
     }
@@ -378,80 +413,66 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
     if (++my_steps > cap) { st |= ST_STEP_LIMIT; break; }
 
     if (!good) {
-      if (!ok && a == identity) {  // matrix.go:478-485
-        a = unknown;
-        newchar = false; eot = false;
-      } else if (a != epsilon && eps_t != 0) {  // matrix.go:487-497
+      if (a != epsilon && eps_t != 0 && !(!ok && a == identity)) {  // matrix.go:487-497
         t0 = eps_t; aux0 = eps_aux;
         eps_t = 0;
-        p = eps_p; rc = eps_r;
+        p = eps_p; rl = eps_rl;
         a = epsilon;
+        newchar = false; eot = false;
+      } else if (!ok && a == identity) {  // matrix.go:478-485
+        a = unknown;
         newchar = false; eot = false;
       } else {  // matrix.go:499-552: drop what is buffered as a token, restart at state 1
         if (a == epsilon) { st |= ST_BAD_MODEL; break; }  // would hand out stale buffer runes
-        if (p <= tp) { p += w; rc++; e = e_next; e_pos = p; }  // matrix.go:515-516
-        if (MODE != MODE_START) {
-          sink.template emit<IS_MATRIX>(tp, EV_TOK_START);
-          sink.template emit<IS_MATRIX>(p, EV_TOK_END);   // matrix.go:528
-        }
+        if (p <= tp) { p += w; rl++; }                    // matrix.go:515-516
+        if (MODE != MODE_START) sink.template token<IS_MATRIX>(tp, p, rl);  // matrix.go:528
         sentence_end = false; text_end = false;
-        ri -= rc; rc = 0; tp = p;                         // matrix.go:537-543
-        eps_t = 0;
         t = t_start; aux = aux_start;                     // matrix.go:548
         newchar = true;
-        SYNC_POINT();
+        REWIND();
         if (stopped) break;
       }
       continue;
     }
 
-    bool rewind = false;
+    newchar = true;
     if (a == epsilon) {  // matrix.go:563-576
       if (p > tp) {
-        if (MODE != MODE_START) {
-          sink.template emit<IS_MATRIX>(tp, EV_TOK_START);
-          sink.template emit<IS_MATRIX>(p, EV_TOK_END);
-        }
-        rewind = true;
+        if (MODE != MODE_START) sink.template token<IS_MATRIX>(tp, p, rl);
         sentence_end = false; text_end = false;
+        REWIND();
+        if (stopped) break;
       } else {
         sentence_end = true;
-        if (MODE != MODE_START) sink.template emit<IS_MATRIX>(p, EV_S_EPS);
+        if (MODE != MODE_START) sink.sentence(p);
       }
     } else {  // matrix.go:579-591
       const bool first = p == tp;
-      p += w; rc++;
-      e = e_next; e_pos = p;
-      if (first && nontoken) tp = p;
-    }
-    if (eot) {  // matrix.go:593-605 / datok.go:1019-1030
-      eot = false;
-      if (!sentence_end) {
+      p += w; rl++;
+      if (first && nontoken) { tp = p; rl = 0; }
+      if (eot) {  // matrix.go:593-605 / datok.go:1019-1030
+        eot = false;
+        if (MODE != MODE_START) sink.template eot<IS_MATRIX>(p, !sentence_end);
         sentence_end = true;
-        if (MODE != MODE_START) sink.template emit<IS_MATRIX>(p, EV_S_EOT);
+        text_end = true;
+        if (IS_MATRIX) {  // matrix.go:601; the double array keeps its window
+          REWIND();
+          if (stopped) break;
+        }
       }
-      text_end = true;
-      if (MODE != MODE_START) sink.template emit<IS_MATRIX>(p, EV_E_EOT);
-      if (IS_MATRIX) rewind = true;  // matrix.go:601; the double array keeps its window
-    }
-    newchar = true;
-    if (rewind) {  // matrix.go:608-627
-      ri -= rc; rc = 0; tp = p;
-      eps_t = 0;
-      SYNC_POINT();
-      if (stopped) break;
     }
   }
-#undef SYNC_POINT
+#undef REWIND
 
-  if (!stopped && MODE != MODE_START && !(st & (ST_STEP_LIMIT | ST_BAD_MODEL))) {
-    if (p > tp) {  // matrix.go:671-678
-      sink.template emit<IS_MATRIX>(tp, EV_TOK_START);
-      sink.template emit<IS_MATRIX>(p, EV_TOK_END);
-      sentence_end = false; text_end = false;
+  if (!stopped && !(st & (ST_STEP_LIMIT | ST_BAD_MODEL))) {
+    if (hi - bs > DTK_WINDOW && count_runes(s, bs, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
+    if (MODE != MODE_START) {
+      if (p > tp) {  // matrix.go:671-678
+        sink.template token<IS_MATRIX>(tp, p, rl);
+        sentence_end = false; text_end = false;
+      }
+      sink.tail(p, sentence_end, text_end);  // matrix.go:683-691
     }
-    if (!sentence_end) sink.template emit<IS_MATRIX>(p, EV_S_EOF);  // matrix.go:683-684
-    if (!text_end) sink.template emit<IS_MATRIX>(p, EV_E_EOF);      // matrix.go:690-691
   }
   st_out = st;
   steps_out = my_steps;
@@ -479,12 +500,11 @@ __global__ __launch_bounds__(WAVE) void k_walk_doc(TRANS tr, DtkWalkArgs A, uint
     const uint64_t off = A.doc_off[d];
     const uint32_t len = (uint32_t)(A.doc_off[d + 1] - off);
     EventSink sink;
-    sink.init(A.evA + off + d, A.evB + off + d, 0u, 0xFFFFFFFFu);
+    sink.init(A.evA + off + d, A.evB + off + d, A.tlen + off + d, 0u, 0xFFFFFFFFu);
     DtkLaneState init{0u, tr.start_state(), tr.start_aux(), 0u}, fin;
     uint32_t st;
-    walk_lane<TRANS, IS_MATRIX, MODE_DOC>(tr, A.sym + off, len, init, 0u, sink, epsilon, unknown,
+    walk_lane<TRANS, IS_MATRIX, MODE_DOC>(tr, A.sym, off, len, init, 0u, sink, epsilon, unknown,
                                           identity, step_cap(A.step_factor, len), fin, st, steps);
-    sink.flush();
     A.status[d] = st | sink.st;
   }
   add_steps(A.steps, steps);
@@ -527,18 +547,18 @@ __global__ __launch_bounds__(WAVE) void k_spec_start(TRANS tr, DtkWalkArgs A, Dt
           while (sp < len && !(s[sp] & DTK_SYM_START)) sp++;
           DtkLaneState init{sp, tr.start_state(), tr.start_aux(), 0u};
           EventSink sink;
-          sink.init(nullptr, nullptr, 0u, 0u);
+          sink.init(nullptr, nullptr, nullptr, 0u, 0u);
           uint32_t st;
-          walk_lane<TRANS, IS_MATRIX, MODE_START>(tr, s, len, init, kc, sink, epsilon, unknown, identity,
-                                                  step_cap(A.step_factor, len), rec, st, steps);
+          walk_lane<TRANS, IS_MATRIX, MODE_START>(tr, A.sym, off, len, init, kc, sink, epsilon, unknown,
+                                                  identity, step_cap(A.step_factor, len), rec, st, steps);
         }
         // sp == 0: the walk from the true initial state; its first sync point at/after kc
         else {
           EventSink sink;
-          sink.init(nullptr, nullptr, 0u, 0u);
+          sink.init(nullptr, nullptr, nullptr, 0u, 0u);
           uint32_t st;
-          walk_lane<TRANS, IS_MATRIX, MODE_START>(tr, s, len, rec, kc, sink, epsilon, unknown, identity,
-                                                  step_cap(A.step_factor, len), rec, st, steps);
+          walk_lane<TRANS, IS_MATRIX, MODE_START>(tr, A.sym, off, len, rec, kc, sink, epsilon, unknown,
+                                                  identity, step_cap(A.step_factor, len), rec, st, steps);
         }
       }
       S.lane_start[L] = rec;
@@ -602,10 +622,9 @@ __global__ __launch_bounds__(WAVE) void k_spec_walk(TRANS tr, DtkWalkArgs A, Dtk
         const uint32_t len = (uint32_t)(A.doc_off[d + 1] - off);
         const DtkLaneState init = S.lane_start[L];
         EventSink sink;
-        sink.init(A.evA + off + d, A.evB + off + d, init.p, pl.wend);
-        walk_lane<TRANS, IS_MATRIX, MODE_CHUNK>(tr, A.sym + off, len, init, pl.stop, sink, epsilon, unknown,
+        sink.init(A.evA + off + d, A.evB + off + d, A.tlen + off + d, init.p, pl.wend);
+        walk_lane<TRANS, IS_MATRIX, MODE_CHUNK>(tr, A.sym, off, len, init, pl.stop, sink, epsilon, unknown,
                                                 identity, step_cap(A.step_factor, len), fin, st, steps);
-        sink.flush();
         st |= sink.st;
         if (sink.dropped) fin.flags |= LANE_F_DROPPED;
       }
@@ -713,6 +732,7 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
   const uint32_t len = (uint32_t)(A.doc_off[d + 1] - off);
   const uint8_t *__restrict__ evA = A.evA + off + d;
   const uint8_t *__restrict__ evB = A.evB + off + d;
+  const uint32_t *__restrict__ tlen = A.tlen + off + d;
   const uint16_t *__restrict__ sym = A.sym + off;
   const uint8_t *__restrict__ txt = A.text + off;
   const bool nl_rule = (A.flags & 16u) != 0;  // NEWLINE_AFTER_EOT
@@ -730,14 +750,13 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
 
   // wave-uniform carries
   uint32_t cR = 0;           // runes started before the tile
-  uint32_t cTE = 0, cTS = 0; // token ends / starts before the tile
+  uint32_t cTE = 0;          // token ends before the tile
   uint32_t cNE = 0, cNSev = 0;  // TextEnd / SentenceEnd calls before the tile
   uint32_t cNSent = 0;       // sentence ints pushed before the tile
   uint32_t cSEatEnd = 0, cEatEnd = 0;  // calls seen when the last token ended
   uint32_t cLastEndR = 0, cLastEndByte = 0;
   int32_t cLastRend = 0;
   uint32_t cBase = 0;        // rune index that maps to offset 0 in the current text
-  uint32_t cStartR = 0;      // rune index of the last TOK_START
   uint32_t cLastER = 0, cLastEByte = 0, cTokAtLastE = 0;
   bool cHaveE = false;
   uint32_t status = 0;
@@ -751,7 +770,6 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
       tb = txt[P];
     }
     const unsigned long long mEND = __ballot(f & EV_TOK_END);
-    const unsigned long long mSTART = __ballot(f & EV_TOK_START);
     const unsigned long long mRS = __ballot(rs);
     const unsigned long long mEEOT = __ballot(f & EV_E_EOT);
     const unsigned long long mEEOF = __ballot(f & EV_E_EOF);
@@ -759,16 +777,15 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
     const unsigned long long mS2 = __ballot(f & EV_S_EPS);
     const unsigned long long mS3 = __ballot(f & EV_S_EPS2);
     const unsigned long long mS4 = __ballot(f & EV_S_EOF);
-    if ((mEND | mSTART | mEEOT | mEEOF | mS1 | mS2 | mS3 | mS4) == 0ull) {
+    if ((mEND | mEEOT | mEEOF | mS1 | mS2 | mS3 | mS4) == 0ull) {
       cR += popc(mRS);
       continue;
     }
 
     // Order of the calls at one position (bit order): S_EOT, E_EOT, TOK_END,
-    // S_EPS, S_EPS2, S_EOF, E_EOF, TOK_START.
+    // S_EPS, S_EPS2, S_EOF, E_EOF.
     const uint32_t R = cR + popc(mRS & lt);
     const uint32_t te = cTE + popc(mEND & lt);   // tokens ended at lower positions
-    const uint32_t ts = cTS + popc(mSTART & lt);
     const bool isEnd = (f & EV_TOK_END) != 0;
     const bool hasEEOT = (f & EV_E_EOT) != 0;
     const uint32_t s1 = (f & EV_S_EOT) ? 1u : 0u;
@@ -808,12 +825,8 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
     const uint32_t tokAtPrevE = haveE ? tokAtE_t : cTokAtLastE;
     const bool anyE = haveE || cHaveE;
 
-    // rune index of the matching TOK_START (strictly below: tokens are never empty)
-    const unsigned long long mPrevStart = mSTART & lt;
-    const int js = mPrevStart ? highest(mPrevStart) : 0;
-    const uint32_t Rs_t = __shfl(R, js);
-    const uint32_t Rs = mPrevStart ? Rs_t : cStartR;
-
+    // byte / rune length of the token that ends here (stored by the walk)
+    const uint32_t tl = isEnd ? tlen[P] : 0u;
     // rune index that counts as offset 0 for the text this token opens
     // (token_writer.go:66-81: posC restarts at 0; the offset handed to Token is
     // counted from the start of the window, which the matrix rewinds to the rune
@@ -832,7 +845,7 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
     const uint32_t baseFrom_t = __shfl(base_mine, jt);
     const uint32_t tbase = text_first ? base_mine : (mPrevTF ? baseFrom_t : cBase);
     const int32_t rend = (int32_t)(R - tbase);
-    const int32_t rstart = (int32_t)(Rs - tbase);
+    const int32_t rstart = rend - (int32_t)(tl >> 16);
 
     // end offset of the last token below this lane / at or below it
     const int32_t rendPrev_t = __shfl(rend, jp);
@@ -853,8 +866,8 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
     const uint32_t excl = wave_excl_scan(c, cTotal);
 
     if (WRITE) {
-      if (f & EV_TOK_START) A.tok_bstart[tok_base + ts] = P;
       if (isEnd) {
+        A.tok_bstart[tok_base + k] = P - (tl & 0xFFFFu);
         A.tok_bend[tok_base + k] = P;
         A.tok_rstart[tok_base + k] = rstart;
         A.tok_rend[tok_base + k] = rend;
@@ -885,7 +898,6 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
       cLastRend = __shfl(rend, jl);
       cBase = __shfl(tbase, jl);
     }
-    if (mSTART) cStartR = __shfl(R, highest(mSTART));
     if (mEEOT) {
       const int jl = highest(mEEOT);
       cLastER = __shfl(R, jl);
@@ -895,7 +907,6 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
     }
     cR += popc(mRS);
     cTE += popc(mEND);
-    cTS += popc(mSTART);
     cNE += popc(mEEOT) + popc(mEEOF);
     cNSev += popc(mS1) + popc(mS2) + popc(mS3) + popc(mS4);
     cNSent += cTotal;

@@ -12,8 +12,7 @@ from ._lib import ModelInfo, ResultView, Totals, check, lib
 TOKENS, SENTENCES, TOKEN_POS, SENTENCE_POS, NEWLINE_AFTER_EOT = 1, 2, 4, 8, 16
 SIMPLE = TOKENS | SENTENCES
 
-EV_S_EOT, EV_E_EOT, EV_TOK_END, EV_S_EPS, EV_S_EPS2, EV_S_EOF, EV_E_EOF, EV_TOK_START = (
-    1, 2, 4, 8, 16, 32, 64, 128)
+EV_S_EOT, EV_E_EOT, EV_TOK_END, EV_S_EPS, EV_S_EPS2, EV_S_EOF, EV_E_EOF = 1, 2, 4, 8, 16, 32, 64
 
 
 # ------------------------------------------------------------------ UTF-8 (Go)
@@ -131,13 +130,13 @@ def new_token_writer(w, flags) -> TokenWriter:
     return tw
 
 
-def replay(is_matrix, text: bytes, events, tw: TokenWriter):
+def replay(is_matrix, text: bytes, events, tok_bstart, tw: TokenWriter):
     """Feeds one document's event bytes to the closures in reference call order.
 
     Int arguments as upstream: the matrix passes buffc (matrix.go:575,597,600,684,691);
     the double array 0, except SentenceEnd(buffc) at EOT (datok.go:1015,1023,1026)."""
     n = len(text)
-    B = start = 0
+    B = k = 0
     nz = np.flatnonzero(np.asarray(events[:n + 1]))
     for p in nz.tolist():
         e = int(events[p])
@@ -150,6 +149,8 @@ def replay(is_matrix, text: bytes, events, tw: TokenWriter):
             if is_matrix:
                 B = p
         if e & EV_TOK_END:
+            start = int(tok_bstart[k])
+            k += 1
             buf = _decode_runes(text[B:p])
             tw.Token(len(_decode_runes(text[B:start])), buf)
             B = p
@@ -158,8 +159,6 @@ def replay(is_matrix, text: bytes, events, tw: TokenWriter):
                 tw.SentenceEnd(buffc() if is_matrix else 0)
         if e & EV_E_EOF:
             tw.TextEnd(buffc() if is_matrix else 0)
-        if e & EV_TOK_START:
-            start = p
 
 
 # ------------------------------------------------------------------- Tokenizer
@@ -200,7 +199,7 @@ class Tokenizer:
             print("datok_amd:", e, file=sys.stderr)
             return False
         self.last_status = int(res.status[0])
-        replay(self.type() == "MATOK", text, res.events, tw)
+        replay(self.type() == "MATOK", text, res.events, res.tok_bstart, tw)
         tw.Flush()                              # `defer w.Flush()`, matrix.go:374
         return True
 

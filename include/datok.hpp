@@ -102,15 +102,16 @@ inline int count_runes(const uint8_t *p, size_t n) {
   return k;
 }
 
-// Replays the event bytes of one document (dtk_result_view.events, n+1 bytes)
+// Replays the event bytes of one document (dtk_result_view.events /
+// events_open, n+1 bytes each, plus the token start offsets of that document)
 // into the closures.  Order at one cursor position = bit order of the byte.
 // The int arguments follow the reference: the matrix passes buffc everywhere
 // (matrix.go:575,597,600,684,691), the double array passes 0 except for the
 // SentenceEnd fired by EOT (datok.go:1015,1023,1026,1119,1127).
 inline void replay(bool is_matrix, const uint8_t *text, size_t n, const uint8_t *ev_close,
-                   const uint8_t *ev_open, TokenWriter &w) {
+                   const uint8_t *ev_open, const uint32_t *tok_bstart, TokenWriter &w) {
   size_t B = 0;      // byte position of the window start (last rewind)
-  size_t start = 0;  // byte position of the pending token start
+  size_t k = 0;      // tokens replayed so far (index into tok_bstart)
   std::vector<rune> buf;
   for (size_t p = 0; p <= n; p++) {
     const uint8_t e = (uint8_t)(ev_close[p] | ev_open[p]);
@@ -122,6 +123,7 @@ inline void replay(bool is_matrix, const uint8_t *text, size_t n, const uint8_t 
       if (is_matrix) B = p;  // matrix.go:601 rewinds, datok.go:1019-1030 does not
     }
     if (e & DTK_EV_TOK_END) {
+      const size_t start = tok_bstart[k++];
       buf.clear();
       int offset = 0;
       size_t i = B;
@@ -139,7 +141,6 @@ inline void replay(bool is_matrix, const uint8_t *text, size_t n, const uint8_t 
     if (e & DTK_EV_S_EPS2) w.SentenceEnd(is_matrix ? buffc() : 0);
     if (e & DTK_EV_S_EOF) w.SentenceEnd(is_matrix ? buffc() : 0);
     if (e & DTK_EV_E_EOF) w.TextEnd(is_matrix ? buffc() : 0);
-    if (e & DTK_EV_TOK_START) start = p;
   }
 }
 
@@ -268,7 +269,7 @@ class GpuTokenizer final : public Tokenizer {
               dtk_batch_result_host(b, &v) == DTK_OK;
     if (ok) {
       last_status_ = v.status[0];
-      detail::replay(Type() == "MATOK", text, n, v.events, v.events_open, w);
+      detail::replay(Type() == "MATOK", text, n, v.events, v.events_open, v.tok_bstart, w);
     }
     dtk_batch_free(b);
     return ok;

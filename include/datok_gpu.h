@@ -171,7 +171,8 @@ typedef struct {
   /* raw walk output, for replay into TokenWriter closures: one byte per byte
    * position of every document plus one (index doc_off[d] + d + p).  The calls
    * fired by a window rewind (S_EOT, E_EOT, TOK_END) are in `events`, all
-   * others in `events_open`; OR the two bytes. */
+   * others in `events_open`; OR the two bytes.  The k-th TOK_END of a document
+   * belongs to its k-th token (tok_bstart/tok_bend). */
   const uint8_t *events;
   const uint8_t *events_open;
 } dtk_result_view;
@@ -188,8 +189,7 @@ enum {
   DTK_EV_S_EPS = 8,      /* SentenceEnd from an epsilon arc on an empty token (matrix.go:574-575) */
   DTK_EV_S_EPS2 = 16,    /* a second one at the same cursor */
   DTK_EV_S_EOF = 32,     /* final SentenceEnd (matrix.go:683-684) */
-  DTK_EV_E_EOF = 64,     /* final TextEnd (matrix.go:690-691) */
-  DTK_EV_TOK_START = 128 /* a token starts at this byte */
+  DTK_EV_E_EOF = 64      /* final TextEnd (matrix.go:690-691) */
 };
 
 /* ---- drop-in for Tokenizer.Transduce / TransduceTokenWriter with a stock
