@@ -357,24 +357,33 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
   uint32_t grp = 0xFFFFFFFEu;    // group index held in q_cur; q_next holds grp + 1 (none yet)
   uint64_t q_cur = 0, q_next = 0;
 
-  // window rewind: matrix.go:537-543 / 608-627.  The 1024-rune limit of the
-  // reference is checked here, where the window was at its longest.
-#define REWIND()                                                                              \
-  do {                                                                                        \
-    if (hi - bs > DTK_WINDOW && count_runes(s, bs, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW; \
-    tp = p; bs = p; rl = 0; eps_t = 0;                                                        \
-    if (MODE != MODE_DOC && p >= stop_pos) {                                                  \
-      fin.p = p; fin.t = t; fin.aux = aux;                                                    \
-      fin.flags = (sentence_end ? LANE_F_SENT : 0u) | (text_end ? LANE_F_TEXT : 0u) |         \
-                  (ok ? LANE_F_OK : 0u);                                                      \
-      stopped = true;                                                                         \
-    }                                                                                         \
-  } while (0)
-
-  for (;;) {
+  // One table lookup per iteration (the reference's loop body, matrix.go:384-635),
+  // written as predicates + selects so that the 64 lanes of a wave, which are all
+  // in different phases of their tokens, share one short instruction stream; only
+  // the stores and the rare paths (EOF drain, EOT, hard fail) are branches.
+  bool done = false;
+  do {
     if (newchar) {
-      if (p >= len) {  // p == hi == len: nothing buffered, reader at EOF
-        // the drain of matrix.go:650-668 / datok.go:1085-1103
+      if (p < len) {
+        const uint32_t i = p + o3, g = i >> 2;
+        if (g != grp) {
+          q_cur = (g == grp + 1u) ? q_next : sq[g];  // else: after a backtrack / at the start
+          q_next = sq[g + 1u];                       // in flight for the next ~4 runes
+          grp = g;
+        }
+        const uint32_t e = (uint32_t)(q_cur >> ((i & 3u) * 16u)) & 0xFFFFu;
+        a = e & DTK_SYM_MASK;
+        w = ((e >> DTK_SYM_W_SHIFT) & 3u) + 1u;
+        const uint32_t cls = (e >> DTK_SYM_CLS_SHIFT) & 3u;
+        hi = max(hi, p + w);             // matrix.go:388-408: runes enter the window once
+        eot = cls == 1u;                 // matrix.go:422
+        ok = cls >= 2u ? cls == 2u : ok; // matrix.go:427: only runes >= 256 write `ok`
+        t0 = t; aux0 = aux;              // matrix.go:437
+        const bool he = tr.has_eps(t0, aux0);  // matrix.go:442-454
+        eps_t = he ? t0 : eps_t; eps_aux = he ? aux0 : eps_aux;
+        eps_p = he ? p : eps_p; eps_rl = he ? rl : eps_rl;
+      } else {
+        // reader at EOF: the drain of matrix.go:650-668 / datok.go:1085-1103
         t0 = t; aux0 = aux;
         a = epsilon;
         newchar = false;
@@ -385,84 +394,69 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
           eps_t = 0;
           p = eps_p; rl = eps_rl;
         } else {
-          break;
-        }
-      } else {
-        const uint32_t i = p + o3, g = i >> 2;
-        if (g != grp) {
-          if (g == grp + 1u) q_cur = q_next; else q_cur = sq[g];   // else: after a backtrack / at start
-          q_next = sq[g + 1u];                                    // in flight for the next ~4 runes
-          grp = g;
-        }
-        const uint32_t e = (uint32_t)(q_cur >> ((i & 3u) * 16u)) & 0xFFFFu;
-        a = e & DTK_SYM_MASK;
-        w = ((e >> DTK_SYM_W_SHIFT) & 3u) + 1u;
-        const uint32_t cls = (e >> DTK_SYM_CLS_SHIFT) & 3u;
-        hi = max(hi, p + w);             // matrix.go:388-408: runes enter the window once
-        eot = cls == 1u;                 // matrix.go:422
-        if (cls >= 2u) ok = cls == 2u;   // matrix.go:427: only runes >= 256 write `ok`
-        t0 = t; aux0 = aux;              // matrix.go:437
-        if (tr.has_eps(t0, aux0)) {      // matrix.go:442-454
-          eps_t = t0; eps_aux = aux0; eps_p = p; eps_rl = rl;
+          done = true;
         }
       }
     }
+    if (!done) {
+      bool nontoken = false;
+      const bool good = tr.step(t0, aux0, a, t, aux, nontoken, st);
+      my_steps++;
 
-    bool nontoken = false;
-    const bool good = tr.step(t0, aux0, a, t, aux, nontoken, st);
-    if (++my_steps > cap) { st |= ST_STEP_LIMIT; break; }
+      const bool is_eps = a == epsilon;
+      const bool retry_unknown = !good && !ok && a == identity;              // matrix.go:478-485
+      const bool backtrack = !good && !retry_unknown && !is_eps && eps_t != 0;  // matrix.go:487-497
+      bool hardfail = !good && !retry_unknown && !backtrack;                 // matrix.go:499-552
+      const bool flush_eps = good && is_eps && p > tp;                       // matrix.go:565-572
+      const bool sent_eps = good && is_eps && p <= tp;                       // matrix.go:573-576
+      const bool advance = good && !is_eps;                                  // matrix.go:579-591
 
-    if (!good) {
-      if (a != epsilon && eps_t != 0 && !(!ok && a == identity)) {  // matrix.go:487-497
-        t0 = eps_t; aux0 = eps_aux;
-        eps_t = 0;
-        p = eps_p; rl = eps_rl;
-        a = epsilon;
-        newchar = false; eot = false;
-      } else if (!ok && a == identity) {  // matrix.go:478-485
-        a = unknown;
-        newchar = false; eot = false;
-      } else {  // matrix.go:499-552: drop what is buffered as a token, restart at state 1
-        if (a == epsilon) { st |= ST_BAD_MODEL; break; }  // would hand out stale buffer runes
-        if (p <= tp) { p += w; rl++; }                    // matrix.go:515-516
-        if (MODE != MODE_START) sink.template token<IS_MATRIX>(tp, p, rl);  // matrix.go:528
-        sentence_end = false; text_end = false;
-        t = t_start; aux = aux_start;                     // matrix.go:548
-        newchar = true;
-        REWIND();
-        if (stopped) break;
+      if (hardfail) {  // rare: drop what is buffered as a token, restart at state 1
+        if (is_eps) { st |= ST_BAD_MODEL; done = true; hardfail = false; }  // stale-buffer case
+        else if (p <= tp) { p += w; rl++; }                                  // matrix.go:515-516
+        t = t_start; aux = aux_start;                                        // matrix.go:548
       }
-      continue;
-    }
-
-    newchar = true;
-    if (a == epsilon) {  // matrix.go:563-576
-      if (p > tp) {
-        if (MODE != MODE_START) sink.template token<IS_MATRIX>(tp, p, rl);
-        sentence_end = false; text_end = false;
-        REWIND();
-        if (stopped) break;
-      } else {
-        sentence_end = true;
-        if (MODE != MODE_START) sink.sentence(p);
+      const bool flush = flush_eps || hardfail;
+      if (MODE != MODE_START) {
+        if (flush) sink.template token<IS_MATRIX>(tp, p, rl);  // matrix.go:528 / 569
+        if (sent_eps) sink.sentence(p);                         // matrix.go:575
       }
-    } else {  // matrix.go:579-591
+      // consume the rune
       const bool first = p == tp;
-      p += w; rl++;
-      if (first && nontoken) { tp = p; rl = 0; }
-      if (eot) {  // matrix.go:593-605 / datok.go:1019-1030
-        eot = false;
+      p = advance ? p + w : p;
+      rl = advance ? rl + 1u : rl;
+      const bool skip = advance && first && nontoken;  // matrix.go:584-588: leading non-token rune
+      tp = skip ? p : tp;
+      rl = skip ? 0u : rl;
+      const bool eot_now = advance && eot;  // matrix.go:593-605 / datok.go:1019-1030
+      if (eot_now) {
         if (MODE != MODE_START) sink.template eot<IS_MATRIX>(p, !sentence_end);
-        sentence_end = true;
-        text_end = true;
-        if (IS_MATRIX) {  // matrix.go:601; the double array keeps its window
-          REWIND();
-          if (stopped) break;
+      }
+      sentence_end = flush ? false : ((sent_eps || eot_now) ? true : sentence_end);
+      text_end = flush ? false : (eot_now ? true : text_end);
+      // retries keep the rune, everything else fetches a new one
+      t0 = backtrack ? eps_t : t0; aux0 = backtrack ? eps_aux : aux0;
+      p = backtrack ? eps_p : p; rl = backtrack ? eps_rl : rl;
+      a = backtrack ? epsilon : (retry_unknown ? unknown : a);
+      newchar = good || hardfail;
+      eot = false;  // consumed above, or cleared by a retry (matrix.go:555)
+      const bool rewind = flush || (IS_MATRIX && eot_now);  // matrix.go:601 vs datok.go:1019-1030
+      eps_t = (backtrack || rewind) ? 0u : eps_t;
+      if (rewind) {  // matrix.go:537-543 / 608-627
+        // the 1024-rune limit of the reference, checked where the window was longest
+        if (hi - bs > DTK_WINDOW && count_runes(s, bs, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
+        tp = p; bs = p; rl = 0;
+        if (MODE != MODE_DOC && p >= stop_pos) {
+          fin.p = p; fin.t = t; fin.aux = aux;
+          fin.flags = (sentence_end ? LANE_F_SENT : 0u) | (text_end ? LANE_F_TEXT : 0u) |
+                      (ok ? LANE_F_OK : 0u);
+          stopped = true;
+          done = true;
         }
       }
+      if (my_steps > cap) { st |= ST_STEP_LIMIT; done = true; }
     }
-  }
-#undef REWIND
+  } while (!done);
 
   if (!stopped && !(st & (ST_STEP_LIMIT | ST_BAD_MODEL))) {
     if (hi - bs > DTK_WINDOW && count_runes(s, bs, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
