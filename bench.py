@@ -217,7 +217,7 @@ def main():
                          "kernel_ms": round(stage_avg["walk"], 4),
                          "lookups_per_launch": int(tot["walk_steps"]),
                          "Glookups_per_s": round(tot["walk_steps"] / walk_s / 1e9, 3)},
-            "stages_ms": {k: round(v, 4) for k, v in stage_avg.items()},
+            "stages_ms": {k: round(v, 4) for k, v in stage_avg.items() if k != "unused"},
             "tokens_per_launch": int(tot["n_tokens"]),
             "walk": {"lanes": int(tot["n_lanes"]), "chunk_bytes": int(tot["chunk_bytes"]), "warm_bytes": args.warm,
                      "repair_rounds": int(tot["repair_rounds"])},

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libdatok_gpu.so")
 
 # error codes / flags (datok_gpu.h)
 OK, E_IO, E_FORMAT, E_NO_DEVICE, E_HIP, E_ARG, E_MODEL, E_CAPACITY, E_STATE = 0, -1, -2, -3, -4, -5, -6, -7, -8
-ST_WINDOW_OVERFLOW, ST_EMPTY_TEXT, ST_BAD_MODEL, ST_IRREGULAR, ST_STEP_LIMIT = 1, 2, 4, 8, 16
+ST_WINDOW_OVERFLOW, ST_EMPTY_TEXT, ST_BAD_MODEL, ST_IRREGULAR, ST_STEP_LIMIT, ST_INTERNAL = 1, 2, 4, 8, 16, 32
 
 EXPORTS = [
     "dtk_device_count", "dtk_set_device", "dtk_strerror", "dtk_last_hip_error",

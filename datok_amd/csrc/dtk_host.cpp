@@ -426,13 +426,16 @@ struct dtk_batch {
   uint32_t chunk = 0;                // chunk size of the current plan (0 = none)
   bool plan_valid = false;
   uint32_t n_lanes = 0, lane_cap = 0;
-  uint32_t *d_lane_doc = nullptr, *d_chunk_off = nullptr, *d_lane_status = nullptr, *d_redo = nullptr;
+  uint32_t *d_lane_doc = nullptr, *d_chunk_off = nullptr, *d_redo = nullptr;
+  uint32_t *d_first_bad = nullptr, *d_fail_lane = nullptr;
+  DtkLaneCount *d_lane_cnt = nullptr;
   DtkLaneState *d_lane_start = nullptr, *d_lane_end = nullptr;
   DtkLanePlan *d_lane_plan = nullptr;
   uint32_t repair_rounds = 0;        // of the last run
   const dtk_model *last_model = nullptr;
   uint32_t last_flags = 0;
   uint64_t *d_tok_off = nullptr, *d_sent_off = nullptr, *d_text_off = nullptr;
+  uint64_t *d_tok_cnt = nullptr, *d_sent_cnt = nullptr, *d_text_cnt = nullptr;  // per-document counts
   uint64_t *d_totals = nullptr;  // [0..3] scan totals, [4] walk steps, [5] documents to repair (u32)
   uint64_t *h_totals = nullptr;  // pinned
   // outputs (grown on demand, never inside a run unless a re-launch is needed)
@@ -503,11 +506,16 @@ extern "C" int dtk_batch_create(uint64_t max_bytes, uint32_t max_docs, dtk_batch
   B_TRY(hipMalloc((void **)&b->d_evB, max_bytes + max_docs + pad));
   B_TRY(hipMalloc((void **)&b->d_tlen, (max_bytes + max_docs + pad) * 4));
   B_TRY(hipMalloc((void **)&b->d_redo, (uint64_t)max_docs * 4));
+  B_TRY(hipMalloc((void **)&b->d_first_bad, (uint64_t)max_docs * 4));
+  B_TRY(hipMalloc((void **)&b->d_fail_lane, (uint64_t)max_docs * 4));
   B_TRY(hipMalloc((void **)&b->d_chunk_off, ((uint64_t)max_docs + 1) * 4));
   B_TRY(hipMalloc((void **)&b->d_status, (uint64_t)max_docs * 4));
   B_TRY(hipMalloc((void **)&b->d_tok_off, ((uint64_t)max_docs + 1) * 8));
   B_TRY(hipMalloc((void **)&b->d_sent_off, ((uint64_t)max_docs + 1) * 8));
   B_TRY(hipMalloc((void **)&b->d_text_off, ((uint64_t)max_docs + 1) * 8));
+  B_TRY(hipMalloc((void **)&b->d_tok_cnt, ((uint64_t)max_docs + 1) * 8));
+  B_TRY(hipMalloc((void **)&b->d_sent_cnt, ((uint64_t)max_docs + 1) * 8));
+  B_TRY(hipMalloc((void **)&b->d_text_cnt, ((uint64_t)max_docs + 1) * 8));
   B_TRY(hipMalloc((void **)&b->d_totals, 8 * 8));
   B_TRY(hipHostMalloc((void **)&b->h_totals, 8 * 8, hipHostMallocDefault));
 #undef B_TRY
@@ -523,7 +531,8 @@ extern "C" void dtk_batch_free(dtk_batch *b) {
   if (!b) return;
   if (b->stream) (void)hipStreamSynchronize(b->stream);
   void *ptrs[] = {b->d_text_own, b->d_off_own, b->d_sym, b->d_evA, b->d_evB, b->d_tlen, b->d_redo, b->d_chunk_off,
-                  b->d_lane_doc, b->d_lane_status, b->d_lane_start, b->d_lane_end, b->d_lane_plan,
+                  b->d_lane_doc, b->d_lane_cnt, b->d_lane_start, b->d_lane_end, b->d_lane_plan,
+                  b->d_first_bad, b->d_fail_lane, b->d_tok_cnt, b->d_sent_cnt, b->d_text_cnt,
                   b->d_status, b->d_tok_off,
                   b->d_sent_off, b->d_text_off, b->d_totals, b->d_rstart, b->d_rend, b->d_sent,
                   b->d_bstart, b->d_bend, b->d_ttok, b->d_tsent};
@@ -620,15 +629,16 @@ static int plan_lanes(dtk_batch *b) {
   for (uint32_t d = 0; d < nd; d++)
     for (uint32_t L = chunk_off[d]; L < chunk_off[d + 1]; L++) lane_doc[L] = d;
   if (lanes > b->lane_cap) {
-    void *old[] = {b->d_lane_doc, b->d_lane_status, b->d_lane_start, b->d_lane_end, b->d_lane_plan};
+    void *old[] = {b->d_lane_doc, b->d_lane_cnt, b->d_lane_start, b->d_lane_end, b->d_lane_plan};
     for (void *p : old)
       if (p) HIP_TRY(hipFree(p));
-    b->d_lane_doc = b->d_lane_status = nullptr;
+    b->d_lane_doc = nullptr;
+    b->d_lane_cnt = nullptr;
     b->d_lane_start = b->d_lane_end = nullptr;
     b->d_lane_plan = nullptr;
     const uint64_t cap = lanes + lanes / 8 + 64;
     HIP_TRY(hipMalloc((void **)&b->d_lane_doc, cap * 4));
-    HIP_TRY(hipMalloc((void **)&b->d_lane_status, cap * 4));
+    HIP_TRY(hipMalloc((void **)&b->d_lane_cnt, cap * sizeof(DtkLaneCount)));
     HIP_TRY(hipMalloc((void **)&b->d_lane_start, cap * sizeof(DtkLaneState)));
     HIP_TRY(hipMalloc((void **)&b->d_lane_end, cap * sizeof(DtkLaneState)));
     HIP_TRY(hipMalloc((void **)&b->d_lane_plan, cap * sizeof(DtkLanePlan)));
@@ -646,6 +656,7 @@ static DtkWalkArgs walk_args(dtk_batch *b) {
   DtkWalkArgs w{};
   w.sym = b->d_sym; w.doc_off = b->d_off; w.n_docs = b->n_docs;
   w.evA = b->d_evA; w.evB = b->d_evB; w.tlen = b->d_tlen; w.status = b->d_status;
+  w.tok_cnt = b->d_tok_cnt; w.sent_cnt = b->d_sent_cnt; w.text_cnt = b->d_text_cnt;
   w.steps = (unsigned long long *)(b->d_totals + 4);
   w.step_factor = 2048;  // look-ahead is bounded by the 1024-rune window (matrix.go:365)
   return w;
@@ -656,7 +667,7 @@ static DtkSpecArgs spec_args(dtk_batch *b, bool redo) {
   s.n_lanes = b->n_lanes; s.chunk = b->chunk; s.warm = b->cfg_warm;
   s.lane_doc = b->d_lane_doc; s.chunk_off = b->d_chunk_off;
   s.lane_start = b->d_lane_start; s.lane_end = b->d_lane_end; s.lane_plan = b->d_lane_plan;
-  s.lane_status = b->d_lane_status;
+  s.lane_cnt = b->d_lane_cnt; s.first_bad = b->d_first_bad; s.fail_lane = b->d_fail_lane;
   s.redo_from = redo ? b->d_redo : nullptr;
   return s;
 }
@@ -693,6 +704,15 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
   HIP_TRY(hipMemsetAsync(b->d_evA, 0, b->total + b->n_docs, s));
   HIP_TRY(hipMemsetAsync(b->d_evB, 0, b->total + b->n_docs, s));
   HIP_TRY(hipMemsetAsync(b->d_totals, 0, 8 * 8, s));
+  if (b->chunk != 0) {
+    // per-document accumulators of the check pass
+    HIP_TRY(hipMemsetAsync(b->d_status, 0, (size_t)b->n_docs * 4, s));
+    HIP_TRY(hipMemsetAsync(b->d_tok_cnt, 0, ((size_t)b->n_docs + 1) * 8, s));
+    HIP_TRY(hipMemsetAsync(b->d_sent_cnt, 0, ((size_t)b->n_docs + 1) * 8, s));
+    HIP_TRY(hipMemsetAsync(b->d_text_cnt, 0, ((size_t)b->n_docs + 1) * 8, s));
+    HIP_TRY(hipMemsetAsync(b->d_first_bad, 0xFF, (size_t)b->n_docs * 4, s));
+    HIP_TRY(hipMemsetAsync(b->d_fail_lane, 0xFF, (size_t)b->n_docs * 4, s));
+  }
   STAGE(1);
   if (dtk_launch_symbolize(b->d_text, b->d_off, b->n_docs, b->total, &m->sig, b->d_sym, s))
     return hip_fail(hipGetLastError(), "symbolize");
@@ -703,7 +723,7 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
   } else {
     DtkSpecArgs sp = spec_args(b, false);
     uint32_t *n_bad = (uint32_t *)(b->d_totals + 5);
-    for (int stage = 0; stage < 4; stage++)
+    for (int stage = 0; stage < 5; stage++)
       if (dtk_launch_spec(&m->tab, &w, &sp, stage, cmp_mask_of(m), b->d_redo, n_bad, s))
         return hip_fail(hipGetLastError(), "speculative walk");
   }
@@ -714,9 +734,10 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
   c.flags = flags & DTK_NEWLINE_AFTER_EOT; c.kind = m->kind;
   c.tok_off = b->d_tok_off; c.sent_off = b->d_sent_off; c.text_off = b->d_text_off;
   c.totals = b->d_totals;
-  if (dtk_launch_compact(&c, 1, s)) return hip_fail(hipGetLastError(), "compact pass 1");
+  // rows are sized by the walk's own counts (no counting pass)
   STAGE(4);
-  if (dtk_launch_scan3(b->d_tok_off, b->d_sent_off, b->d_text_off, b->n_docs, b->d_totals, b->d_status, s))
+  if (dtk_launch_scan3(b->d_tok_cnt, b->d_sent_cnt, b->d_text_cnt, b->d_tok_off, b->d_sent_off, b->d_text_off,
+                       b->n_docs, b->d_totals, b->d_status, s))
     return hip_fail(hipGetLastError(), "scan");
   STAGE(5);
   b->last_args = c;
@@ -769,7 +790,7 @@ static int finish(dtk_batch *b) {
       b->repair_rounds++;
       DtkSpecArgs sp = spec_args(b, true);
       HIP_TRY(hipMemsetAsync(n_bad, 0, 8, s));
-      const int order[4] = {4, 1, 2, 3};
+      const int order[4] = {5, 6, 2, 7};
       for (int stage : order)
         if (dtk_launch_spec(&m->tab, &w, &sp, stage, cmp_mask_of(m), b->d_redo, n_bad, s))
           return hip_fail(hipGetLastError(), "speculative repair");
@@ -777,9 +798,8 @@ static int finish(dtk_batch *b) {
       HIP_TRY(hipStreamSynchronize(s));
       if (b->repair_rounds > 1000000u) return DTK_E_STATE;
     }
-    DtkCompactArgs c = b->last_args;
-    if (dtk_launch_compact(&c, 1, s)) return hip_fail(hipGetLastError(), "compact pass 1");
-    if (dtk_launch_scan3(b->d_tok_off, b->d_sent_off, b->d_text_off, b->n_docs, b->d_totals, b->d_status, s))
+    if (dtk_launch_scan3(b->d_tok_cnt, b->d_sent_cnt, b->d_text_cnt, b->d_tok_off, b->d_sent_off, b->d_text_off,
+                       b->n_docs, b->d_totals, b->d_status, s))
       return hip_fail(hipGetLastError(), "scan");
     int rc = launch_compact2(b);
     if (rc != DTK_OK) return rc;

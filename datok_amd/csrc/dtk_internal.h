@@ -42,6 +42,7 @@
 #define ST_BAD_MODEL 4u
 #define ST_IRREGULAR 8u
 #define ST_STEP_LIMIT 16u
+#define ST_INTERNAL 32u  // the walk's counts and the compaction disagree (a bug, never expected)
 
 struct DtkSigmaDev {
   const uint16_t *ascii;  // [256] symbol per rune < 256 (identity pre-filled, matrix.go:289-293)
@@ -97,6 +98,10 @@ struct DtkLanePlan {
   uint32_t mode;   // PLAN_*
   uint32_t pad;
 };
+struct DtkLaneCount {
+  uint32_t tok, sent, text;  // Token calls, ints of the sentence list, TextEnd calls
+  uint32_t status;
+};
 struct DtkSpecArgs {
   uint32_t n_lanes;
   uint32_t chunk, warm;             // chunk size C and warm-up overlap W in bytes
@@ -105,7 +110,9 @@ struct DtkSpecArgs {
   struct DtkLaneState *lane_start;  // record each lane starts from
   struct DtkLaneState *lane_end;    // where it stopped
   struct DtkLanePlan *lane_plan;
-  uint32_t *lane_status;
+  struct DtkLaneCount *lane_cnt;
+  uint32_t *first_bad;              // per document: first chunk without a linked successor
+  uint32_t *fail_lane;              // per document: first lane that missed its successor's record
   const uint32_t *redo_from;        // repair rounds: first lane to redo per document, or null
 };
 
@@ -116,6 +123,7 @@ struct DtkWalkArgs {
   uint8_t *evA, *evB;       // closing / opening event bytes, zero-filled; index doc_off[d] + d + p
   uint32_t *tlen;           // token byte length | rune length << 16, at the token's end position
   uint32_t *status;         // per document, OR-ed
+  uint64_t *tok_cnt, *sent_cnt, *text_cnt;  // per document: what the writer would have collected
   unsigned long long *steps;  // global lookup counter
   uint32_t step_factor;     // cap = step_factor * (len + 2) lookups per document
 };
@@ -152,8 +160,8 @@ int dtk_launch_spec(const struct DtkTableDev *tab, const struct DtkWalkArgs *arg
                     const struct DtkSpecArgs *spec, int stage, uint32_t cmp_mask, uint32_t *redo_out,
                     uint32_t *n_bad, void *stream);
 int dtk_launch_compact(const struct DtkCompactArgs *args, int pass, void *stream);
-int dtk_launch_scan3(uint64_t *a, uint64_t *b, uint64_t *c, uint32_t n_docs, uint64_t *totals,
-                     const uint32_t *status, void *stream);
+int dtk_launch_scan3(const uint64_t *ca, const uint64_t *cb, const uint64_t *cc, uint64_t *a, uint64_t *b,
+                     uint64_t *c, uint32_t n_docs, uint64_t *totals, const uint32_t *status, void *stream);
 #ifdef __cplusplus
 }
 #endif

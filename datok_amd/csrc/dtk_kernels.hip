@@ -256,17 +256,24 @@ struct EventSink {
   uint32_t last_eot_p, eot_bits;  // position / byte of the last EOT pair (double array merge)
   uint32_t st;
   bool dropped;
+  // what NewTokenWriter would have collected from this lane's calls
+  // (token_writer.go:72-81, 104-109, 131-159): tokens, ints of the sentence list, texts
+  uint32_t c_tok, c_sent, c_text;
   __device__ __forceinline__ void init(uint8_t *a, uint8_t *b, uint32_t *tl, uint32_t wlo, uint32_t whi) {
     evA = a; evB = b; tlen = tl; lo = wlo; hi = whi;
     last_s_p = last_eot_p = 0xFFFFFFFFu; s_bits = eot_bits = 0; st = 0; dropped = false;
+    c_tok = c_sent = c_text = 0;
   }
   __device__ __forceinline__ bool in_closing(uint32_t p) const { return p > lo && p <= hi; }
   __device__ __forceinline__ bool in_opening(uint32_t p) const { return p >= lo && p < hi; }
 
   // Token(bufft, buffer[:buffc]) -- matrix.go:528,569,675
+  // sent_first: no token since the last SentenceEnd / TextEnd (the writer's sentB)
   template <bool IS_MATRIX>
-  __device__ __forceinline__ void token(uint32_t tp, uint32_t p, uint32_t rl) {
+  __device__ __forceinline__ void token(uint32_t tp, uint32_t p, uint32_t rl, bool sent_first) {
     if (!in_closing(p)) { dropped = true; return; }
+    c_tok++;
+    c_sent += sent_first ? 1u : 0u;
     uint32_t bits = EV_TOK_END;
     if (!IS_MATRIX && p == last_eot_p) bits |= eot_bits;
     evA[p] = (uint8_t)bits;
@@ -274,17 +281,21 @@ struct EventSink {
     tlen[p] = (bl > 0xFFFFu ? 0xFFFFu : bl) | ((rl > 0xFFFFu ? 0xFFFFu : rl) << 16);
   }
   // SentenceEnd? + TextEnd fired by an EOT rune -- matrix.go:593-600
+  // has_tok: the current text has a token (else the reference panics in position modes)
   template <bool IS_MATRIX>
-  __device__ __forceinline__ void eot(uint32_t p, bool with_sentence) {
+  __device__ __forceinline__ void eot(uint32_t p, bool with_sentence, bool has_tok) {
     if (!in_closing(p)) { dropped = true; return; }
+    c_text++;
+    if (has_tok) c_sent += with_sentence ? 1u : 0u; else st |= ST_EMPTY_TEXT;
     if (!IS_MATRIX && p == last_eot_p) st |= ST_IRREGULAR;  // the same EOT consumed twice
     const uint32_t bits = EV_E_EOT | (with_sentence ? EV_S_EOT : 0u);
     if (!IS_MATRIX) { last_eot_p = p; eot_bits = bits; }
     evA[p] = (uint8_t)bits;
   }
   // SentenceEnd from an epsilon arc on an empty token -- matrix.go:574-575
-  __device__ __forceinline__ void sentence(uint32_t p) {
+  __device__ __forceinline__ void sentence(uint32_t p, bool has_tok) {
     if (!in_opening(p)) { dropped = true; return; }
+    if (has_tok) c_sent++; else st |= ST_EMPTY_TEXT;
     if (p == last_s_p) {
       if (s_bits & EV_S_EPS2) st |= ST_IRREGULAR;
       s_bits |= EV_S_EPS2;
@@ -295,10 +306,12 @@ struct EventSink {
     evB[p] = (uint8_t)s_bits;
   }
   // final SentenceEnd / TextEnd -- matrix.go:683-691
-  __device__ __forceinline__ void tail(uint32_t p, bool sentence_end, bool text_end) {
+  __device__ __forceinline__ void tail(uint32_t p, bool sentence_end, bool text_end, bool has_tok) {
     const uint32_t bits = (sentence_end ? 0u : EV_S_EOF) | (text_end ? 0u : EV_E_EOF);
     if (!bits) return;
     if (!in_opening(p)) { dropped = true; return; }
+    if (!text_end) c_text++;
+    if (has_tok) c_sent += sentence_end ? 0u : 1u; else st |= ST_EMPTY_TEXT;
     evB[p] = (uint8_t)(bits | (p == last_s_p ? s_bits : 0u));
   }
 };
@@ -353,6 +366,11 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
   uint32_t st = 0, my_steps = 0;
   fin.p = 0xFFFFFFFFu; fin.t = 0; fin.aux = 0; fin.flags = 0;
   bool stopped = false;
+  // NewTokenWriter state that the counts need.  A lane starts right after a rewind:
+  // p > 0 means a token was flushed or an EOT fired there, so "a token exists in the
+  // document" is p > 0 and "in the current text" additionally needs !textEnd.
+  bool any_tok = init.p > 0;               // some Token call happened (else sentB is still true)
+  bool has_tok = init.p > 0 && !text_end;  // pos[] of the current text is not empty
 
   uint32_t grp = 0xFFFFFFFEu;    // group index held in q_cur; q_next holds grp + 1 (none yet)
   uint64_t q_cur = 0, q_next = 0;
@@ -418,9 +436,12 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
       }
       const bool flush = flush_eps || hardfail;
       if (MODE != MODE_START) {
-        if (flush) sink.template token<IS_MATRIX>(tp, p, rl);  // matrix.go:528 / 569
-        if (sent_eps) sink.sentence(p);                         // matrix.go:575
+        if (flush)  // matrix.go:528 / 569
+          sink.template token<IS_MATRIX>(tp, p, rl, sentence_end || text_end || !any_tok);
+        if (sent_eps) sink.sentence(p, has_tok);  // matrix.go:575
       }
+      any_tok = any_tok || flush;
+      has_tok = has_tok || flush;
       // consume the rune
       const bool first = p == tp;
       p = advance ? p + w : p;
@@ -430,7 +451,8 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
       rl = skip ? 0u : rl;
       const bool eot_now = advance && eot;  // matrix.go:593-605 / datok.go:1019-1030
       if (eot_now) {
-        if (MODE != MODE_START) sink.template eot<IS_MATRIX>(p, !sentence_end);
+        if (MODE != MODE_START) sink.template eot<IS_MATRIX>(p, !sentence_end, has_tok);
+        has_tok = false;  // TextEnd: pos = pos[:0] (token_writer.go:158)
       }
       sentence_end = flush ? false : ((sent_eps || eot_now) ? true : sentence_end);
       text_end = flush ? false : (eot_now ? true : text_end);
@@ -462,10 +484,11 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
     if (hi - bs > DTK_WINDOW && count_runes(s, bs, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
     if (MODE != MODE_START) {
       if (p > tp) {  // matrix.go:671-678
-        sink.template token<IS_MATRIX>(tp, p, rl);
+        sink.template token<IS_MATRIX>(tp, p, rl, sentence_end || text_end || !any_tok);
         sentence_end = false; text_end = false;
+        has_tok = true;
       }
-      sink.tail(p, sentence_end, text_end);  // matrix.go:683-691
+      sink.tail(p, sentence_end, text_end, has_tok);  // matrix.go:683-691
     }
   }
   st_out = st;
@@ -500,6 +523,7 @@ __global__ __launch_bounds__(WAVE) void k_walk_doc(TRANS tr, DtkWalkArgs A, uint
     walk_lane<TRANS, IS_MATRIX, MODE_DOC>(tr, A.sym, off, len, init, 0u, sink, epsilon, unknown,
                                           identity, step_cap(A.step_factor, len), fin, st, steps);
     A.status[d] = st | sink.st;
+    A.tok_cnt[d] = sink.c_tok; A.sent_cnt[d] = sink.c_sent; A.text_cnt[d] = sink.c_text;
   }
   add_steps(A.steps, steps);
 }
@@ -567,10 +591,13 @@ __global__ __launch_bounds__(256) void k_spec_plan(DtkWalkArgs A, DtkSpecArgs S)
   const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d >= A.n_docs) return;
   const uint32_t L0 = S.chunk_off[d], L1 = S.chunk_off[d + 1];
-  uint32_t first = L0;
-  if (S.redo_from) {
-    if (S.redo_from[d] == 0xFFFFFFFFu) return;
-    first = S.redo_from[d];
+  if (S.redo_from[d] == 0xFFFFFFFFu) return;
+  // lanes before the first redone lane are chained by construction (they checked out)
+  const uint32_t first = S.redo_from[d];
+  for (uint32_t L = L0; L < first; L++) {
+    DtkLanePlan pl;
+    pl.stop = pl.wend = S.lane_start[L + 1].p; pl.mode = PLAN_CHAINED; pl.pad = 0;
+    S.lane_plan[L] = pl;
   }
   bool enabled = true;
   for (uint32_t L = first; L < L1; L++) {
@@ -598,6 +625,45 @@ __global__ __launch_bounds__(256) void k_spec_plan(DtkWalkArgs A, DtkSpecArgs S)
   }
 }
 
+// First pass: every lane derives its window from the start records and
+// first_bad[d] (k_spec_link).  Repair rounds: from lane_plan (k_spec_plan).
+__device__ __forceinline__ DtkLanePlan plan_of(const DtkSpecArgs &S, uint32_t L, uint32_t d) {
+  if (S.redo_from) return S.lane_plan[L];
+  const uint32_t L0 = S.chunk_off[d], L1 = S.chunk_off[d + 1];
+  const uint32_t k = L - L0, fb = S.first_bad[d];
+  DtkLanePlan pl;
+  pl.pad = 0;
+  if (k < fb) {
+    pl.stop = pl.wend = S.lane_start[L + 1].p;
+    pl.mode = PLAN_CHAINED;
+  } else if (k == fb) {
+    // last enabled lane: stops at the first sync point behind its own chunk (or EOF)
+    pl.stop = (L + 1 < L1) ? (k + 1u) * S.chunk : 0xFFFFFFFFu;
+    pl.wend = 0xFFFFFFFFu;
+    pl.mode = PLAN_LAST;
+  } else {
+    pl.stop = pl.wend = 0;
+    pl.mode = PLAN_OFF;
+  }
+  return pl;
+}
+
+// One thread per lane: is my successor's record present and not before mine?
+// first_bad[d] (preset to 0xFFFFFFFF) becomes the first chunk index without such a
+// successor; the last lane of a document never has one.
+__global__ __launch_bounds__(256) void k_spec_link(DtkSpecArgs S) {
+  const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
+  if (L >= S.n_lanes) return;
+  const uint32_t d = S.lane_doc[L];
+  const uint32_t L0 = S.chunk_off[d], L1 = S.chunk_off[d + 1];
+  bool linked = false;
+  if (L + 1 < L1) {
+    const uint32_t np = S.lane_start[L + 1].p, mp = S.lane_start[L].p;
+    linked = np != 0xFFFFFFFFu && mp != 0xFFFFFFFFu && np >= mp;
+  }
+  if (!linked) atomicMin(&S.first_bad[d], L - L0);
+}
+
 template <typename TRANS, bool IS_MATRIX>
 __global__ __launch_bounds__(WAVE) void k_spec_walk(TRANS tr, DtkWalkArgs A, DtkSpecArgs S,
                                                     uint32_t epsilon, uint32_t unknown,
@@ -608,78 +674,119 @@ __global__ __launch_bounds__(WAVE) void k_spec_walk(TRANS tr, DtkWalkArgs A, Dtk
     const uint32_t d = S.lane_doc[L];
     const bool redo = S.redo_from != nullptr;
     if (!redo || (S.redo_from[d] != 0xFFFFFFFFu && L >= S.redo_from[d])) {
-      const DtkLanePlan pl = S.lane_plan[L];
+      const DtkLanePlan pl = plan_of(S, L, d);
       DtkLaneState fin{0xFFFFFFFFu, 0u, 0u, LANE_F_IDLE};
-      uint32_t st = 0;
+      DtkLaneCount cnt{0u, 0u, 0u, 0u};
       if (pl.mode != PLAN_OFF) {
         const uint64_t off = A.doc_off[d];
         const uint32_t len = (uint32_t)(A.doc_off[d + 1] - off);
         const DtkLaneState init = S.lane_start[L];
         EventSink sink;
         sink.init(A.evA + off + d, A.evB + off + d, A.tlen + off + d, init.p, pl.wend);
+        uint32_t st = 0;
         walk_lane<TRANS, IS_MATRIX, MODE_CHUNK>(tr, A.sym, off, len, init, pl.stop, sink, epsilon, unknown,
                                                 identity, step_cap(A.step_factor, len), fin, st, steps);
-        st |= sink.st;
         if (sink.dropped) fin.flags |= LANE_F_DROPPED;
+        cnt.tok = sink.c_tok; cnt.sent = sink.c_sent; cnt.text = sink.c_text; cnt.status = st | sink.st;
       }
       S.lane_end[L] = fin;
-      S.lane_status[L] = st;
+      S.lane_cnt[L] = cnt;
     }
   }
   add_steps(A.steps, steps);
 }
 
-// One thread per document: did every lane arrive exactly at its successor's
-// record?  Writes status[d]; on failure records the first bad lane in
-// redo_from[d], replaces the successor's record by the true state and counts the
-// document in *n_bad.
+// One thread per lane: did I arrive exactly at my successor's record (position,
+// state, flags)?  Lanes that did add their counts / status to the document; the
+// first lane that did not is recorded in fail_lane[d] (preset to 0xFFFFFFFF).
+__global__ __launch_bounds__(256) void k_spec_verify(DtkWalkArgs A, DtkSpecArgs S, uint32_t cmp_mask) {
+  const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
+  if (L >= S.n_lanes) return;
+  const uint32_t d = S.lane_doc[L];
+  const uint32_t L0 = S.chunk_off[d];
+  const uint32_t k = L - L0, fb = S.first_bad[d];
+  if (k > fb) {
+    // a lane behind the chain: legitimate only if the chain ran to EOF and I found no sync point
+    if (S.lane_start[L].p != 0xFFFFFFFFu) atomicMin(&S.fail_lane[d], L0 + fb);
+    return;
+  }
+  const DtkLaneState en = S.lane_end[L];
+  bool good;
+  if (k < fb) {
+    const DtkLaneState nx = S.lane_start[L + 1];
+    good = en.p == nx.p && en.t == nx.t && ((en.flags ^ nx.flags) & cmp_mask) == 0 &&
+           !(en.flags & LANE_F_DROPPED);
+  } else {
+    good = en.p == 0xFFFFFFFFu && !(en.flags & LANE_F_IDLE);  // the chain's last lane must reach EOF
+  }
+  if (!good) { atomicMin(&S.fail_lane[d], L); return; }
+  const DtkLaneCount c = S.lane_cnt[L];
+  if (c.tok) atomicAdd((unsigned long long *)&A.tok_cnt[d], (unsigned long long)c.tok);
+  if (c.sent) atomicAdd((unsigned long long *)&A.sent_cnt[d], (unsigned long long)c.sent);
+  if (c.text) atomicAdd((unsigned long long *)&A.text_cnt[d], (unsigned long long)c.text);
+  if (c.status) atomicOr(&A.status[d], c.status);
+}
+
+// One thread per document: nothing to do unless a lane failed; then the lane
+// `bad` started from a true state (every lane before it checked out), so where it
+// really ended is the true record of its successor: redo from `bad` on.
+__device__ __forceinline__ void mark_redo(const DtkSpecArgs &S, uint32_t d, uint32_t bad, uint32_t *redo_out,
+                                          uint32_t *n_bad) {
+  const uint32_t L1 = S.chunk_off[d + 1];
+  DtkLaneState en = S.lane_end[bad];
+  en.flags &= (LANE_F_SENT | LANE_F_TEXT | LANE_F_OK);
+  if (en.p == 0xFFFFFFFFu) {  // ran to EOF: no later lane has a sync point
+    for (uint32_t M = bad + 1; M < L1; M++) S.lane_start[M].p = 0xFFFFFFFFu;
+  } else if (bad + 1 < L1) {
+    S.lane_start[bad + 1] = en;
+  }
+  redo_out[d] = bad;
+  atomicAdd(n_bad, 1u);
+}
+
+__global__ __launch_bounds__(256) void k_spec_fix(DtkWalkArgs A, DtkSpecArgs S, uint32_t *redo_out,
+                                                  uint32_t *n_bad) {
+  const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= A.n_docs) return;
+  const uint32_t bad = S.fail_lane[d];
+  if (bad == 0xFFFFFFFFu) { redo_out[d] = 0xFFFFFFFFu; return; }
+  mark_redo(S, d, bad, redo_out, n_bad);
+}
+
+// Repair rounds only (one thread per repaired document): did every lane arrive
+// exactly at its successor's record?  If so the document's counts and status are
+// re-assigned from its lanes; otherwise the next bad lane is recorded.
 __global__ __launch_bounds__(256) void k_spec_check(DtkWalkArgs A, DtkSpecArgs S, uint32_t cmp_mask,
                                                     uint32_t *redo_out, uint32_t *n_bad) {
   const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d >= A.n_docs) return;
-  if (S.redo_from && S.redo_from[d] == 0xFFFFFFFFu) { return; }
+  if (S.redo_from[d] == 0xFFFFFFFFu) return;
   const uint32_t L0 = S.chunk_off[d], L1 = S.chunk_off[d + 1];
   uint32_t st = 0, bad = 0xFFFFFFFFu;
+  unsigned long long ntok = 0, nsent = 0, ntext = 0;
   for (uint32_t L = L0; L < L1; L++) {
     const DtkLanePlan pl = S.lane_plan[L];
     const DtkLaneState en = S.lane_end[L];
-    if (pl.mode == PLAN_OFF) {
-      // only reachable when the chain ended legitimately (checked below at PLAN_LAST)
-      continue;
-    }
-    st |= S.lane_status[L];
+    if (pl.mode == PLAN_OFF) continue;  // behind the chain; judged at its PLAN_LAST lane
+    const DtkLaneCount c = S.lane_cnt[L];
+    st |= c.status; ntok += c.tok; nsent += c.sent; ntext += c.text;
     if (pl.mode == PLAN_CHAINED) {
       const DtkLaneState nx = S.lane_start[L + 1];
       const bool same = en.p == nx.p && en.t == nx.t && ((en.flags ^ nx.flags) & cmp_mask) == 0 &&
                         !(en.flags & LANE_F_DROPPED);
       if (!same) { bad = L; break; }
-    } else {  // PLAN_LAST
-      if (L + 1 < L1) {
-        // fine only if this lane ran to EOF and no later lane found a sync point
-        bool fine = en.p == 0xFFFFFFFFu;
-        for (uint32_t M = L + 1; fine && M < L1; M++) fine = S.lane_start[M].p == 0xFFFFFFFFu;
-        if (!fine) { bad = L; break; }
-      } else if (en.p != 0xFFFFFFFFu) {
-        bad = L;  // the last lane of a document must finish the document
-        break;
-      }
+    } else {  // PLAN_LAST: must have run to EOF, and no later lane may claim a sync point
+      bool fine = en.p == 0xFFFFFFFFu;
+      for (uint32_t M = L + 1; fine && M < L1; M++) fine = S.lane_start[M].p == 0xFFFFFFFFu;
+      if (!fine) { bad = L; break; }
     }
   }
   if (bad == 0xFFFFFFFFu) {
     A.status[d] = st;
+    A.tok_cnt[d] = ntok; A.sent_cnt[d] = nsent; A.text_cnt[d] = ntext;
     redo_out[d] = 0xFFFFFFFFu;
   } else {
-    // the lane `bad` started from a true state (all lanes before it checked out): where it
-    // really ended is the true record of its successor.  Redo from `bad` on.
-    DtkLaneState en = S.lane_end[bad];
-    en.flags &= (LANE_F_SENT | LANE_F_TEXT | LANE_F_OK);
-    if (en.p == 0xFFFFFFFFu) {  // ran to EOF: no later lane has a sync point
-      for (uint32_t M = bad + 1; M < L1; M++) S.lane_start[M].p = 0xFFFFFFFFu;
-    } else if (bad + 1 < L1) {
-      S.lane_start[bad + 1] = en;
-    }
-    redo_out[d] = bad;
-    atomicAdd(n_bad, 1u);
+    mark_redo(S, d, bad, redo_out, n_bad);
   }
 }
 
@@ -734,12 +841,13 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
   const uint32_t lane = lane_id();
   const unsigned long long lt = lanemask_lt();
 
-  uint64_t tok_base = 0, sent_base = 0, text_base = 0;
+  uint64_t tok_base = 0, sent_base = 0, text_base = 0, tok_lim = 0, sent_lim = 0, text_lim = 0;
   if (WRITE) {
     // rows were sized by pass 1 + scan; skip everything if the output arrays are too
     // small (the host grows them and re-launches this pass)
     if (A.totals[0] > A.tok_cap || A.totals[1] > A.sent_cap || A.totals[2] > A.text_cap) return;
     tok_base = A.tok_off[d]; sent_base = A.sent_off[d]; text_base = A.text_off[d];
+    tok_lim = A.tok_off[d + 1]; sent_lim = A.sent_off[d + 1]; text_lim = A.text_off[d + 1];
   }
 
   // wave-uniform carries
@@ -860,26 +968,35 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
     const uint32_t excl = wave_excl_scan(c, cTotal);
 
     if (WRITE) {
-      if (isEnd) {
+      if (isEnd && tok_base + k < tok_lim) {
         A.tok_bstart[tok_base + k] = P - (tl & 0xFFFFu);
         A.tok_bend[tok_base + k] = P;
         A.tok_rstart[tok_base + k] = rstart;
         A.tok_rend[tok_base + k] = rend;
       }
       uint64_t si = sent_base + cNSent + excl;
-      if (s1_valid) A.sent[si++] = rendBelow;         // token_writer.go:108
-      if (sent_first) A.sent[si++] = rstart;          // token_writer.go:76-79
-      for (uint32_t q = 0; q < sLate_valid; q++) A.sent[si++] = rendLate;
+      if (si + c <= sent_lim) {
+        if (s1_valid) A.sent[si++] = rendBelow;         // token_writer.go:108
+        if (sent_first) A.sent[si++] = rstart;          // token_writer.go:76-79
+        for (uint32_t q = 0; q < sLate_valid; q++) A.sent[si++] = rendLate;
+      } else if (c) {
+        status |= ST_INTERNAL;
+      }
       if (hasEEOT) {
         const uint64_t ti = text_base + eBeforeEnd - 1u;
-        A.text_tok_end[ti] = te;
-        A.text_sent_end[ti] = cNSent + excl + s1_valid;
+        if (ti < text_lim) {
+          A.text_tok_end[ti] = te;
+          A.text_sent_end[ti] = cNSent + excl + s1_valid;
+        } else status |= ST_INTERNAL;
       }
       if (f & EV_E_EOF) {
         const uint64_t ti = text_base + eBeforeEnd;
-        A.text_tok_end[ti] = tokLate;
-        A.text_sent_end[ti] = cNSent + excl + c;
+        if (ti < text_lim) {
+          A.text_tok_end[ti] = tokLate;
+          A.text_sent_end[ti] = cNSent + excl + c;
+        } else status |= ST_INTERNAL;
       }
+      if (isEnd && tok_base + k >= tok_lim) status |= ST_INTERNAL;
     }
 
     // carries for the next tile
@@ -906,30 +1023,33 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
     cNSent += cTotal;
   }
 
-  const unsigned long long anyst = __ballot(status != 0);
-  if (!WRITE) {
-    uint32_t stw = 0;
-    // OR-reduce status over the wave
-    uint32_t sred = status;
+  // Pass 1 (WRITE == false) is only kept as a cross-check tool; the pipeline sizes the
+  // rows from the walk's own counts.  Either way the counts must agree with this pass.
+  uint32_t sred = status;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sred |= __shfl_down(sred, o);
-    stw = __shfl(sred, 0);
-    if (lane == 0) {
+  for (int o = 32; o > 0; o >>= 1) sred |= __shfl_down(sred, o);
+  sred = __shfl(sred, 0);
+  if (lane == 0) {
+    if (!WRITE) {
       A.tok_off[d] = cTE;
       A.sent_off[d] = cNSent;
       A.text_off[d] = cNE;
-      if (anyst) A.status[d] |= stw;
+    } else if (tok_base + cTE != tok_lim || sent_base + cNSent != sent_lim || text_base + cNE != text_lim) {
+      sred |= ST_INTERNAL;
     }
+    if (WRITE) sred &= ST_INTERNAL;  // everything else was reported by the walk already
+    if (sred) atomicOr(&A.status[d], sred);
   }
 }
 
 // ------------------------------------------------------- exclusive scan (x3)
 //
-// Turns the per-document counts into CSR row offsets (in place, totals at
-// [n_docs]) and counts flagged documents.  One 1024-thread block; each thread
+// Turns the per-document counts into CSR row offsets (totals at [n_docs]) and
+// counts flagged documents.  One 1024-thread block; each thread
 // owns a contiguous slice, a block-level scan links the slices.
 
-__global__ __launch_bounds__(1024) void k_scan3(uint64_t *a, uint64_t *b, uint64_t *c, uint32_t n,
+__global__ __launch_bounds__(1024) void k_scan3(const uint64_t *ca, const uint64_t *cb, const uint64_t *cc,
+                                                uint64_t *a, uint64_t *b, uint64_t *c, uint32_t n,
                                                 uint64_t *totals, const uint32_t *status) {
   __shared__ uint64_t sh[3][1024];
   __shared__ uint32_t shf[1024];
@@ -939,7 +1059,7 @@ __global__ __launch_bounds__(1024) void k_scan3(uint64_t *a, uint64_t *b, uint64
   const uint32_t hi = lo + per < n ? lo + per : n;
   uint64_t sa = 0, sb = 0, sc = 0;
   uint32_t fl = 0;
-  for (uint32_t i = lo; i < hi; i++) { sa += a[i]; sb += b[i]; sc += c[i]; fl += status[i] != 0; }
+  for (uint32_t i = lo; i < hi; i++) { sa += ca[i]; sb += cb[i]; sc += cc[i]; fl += status[i] != 0; }
   sh[0][tid] = sa; sh[1][tid] = sb; sh[2][tid] = sc; shf[tid] = fl;
   __syncthreads();
   for (uint32_t o = 1; o < T; o <<= 1) {
@@ -951,9 +1071,8 @@ __global__ __launch_bounds__(1024) void k_scan3(uint64_t *a, uint64_t *b, uint64
   }
   uint64_t ra = sh[0][tid] - sa, rb = sh[1][tid] - sb, rc = sh[2][tid] - sc;
   for (uint32_t i = lo; i < hi; i++) {
-    uint64_t va = a[i], vb = b[i], vc = c[i];
     a[i] = ra; b[i] = rb; c[i] = rc;
-    ra += va; rb += vb; rc += vc;
+    ra += ca[i]; rb += cb[i]; rc += cc[i];
   }
   if (tid == T - 1) {
     a[n] = sh[0][tid]; b[n] = sh[1][tid]; c[n] = sh[2][tid];
@@ -1002,13 +1121,15 @@ extern "C" int dtk_launch_walk(const DtkTableDev *tab, const DtkWalkArgs *args, 
   });
 }
 
-// stage: 0 start records, 1 plan, 2 walk, 3 check (redo_out / n_bad), 4 clear (repair only)
+// stage: 0 start records, 1 link, 2 walk, 3 verify, 4 fix (first pass);
+//        5 clear, 6 plan, 2 walk, 7 check (repair rounds, spec->redo_from set)
 extern "C" int dtk_launch_spec(const DtkTableDev *tab, const DtkWalkArgs *args, const DtkSpecArgs *spec,
                                int stage, uint32_t cmp_mask, uint32_t *redo_out, uint32_t *n_bad,
                                void *stream) {
   if (args->n_docs == 0 || spec->n_lanes == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const uint32_t lane_blocks = (spec->n_lanes + WAVE - 1) / WAVE;
+  const uint32_t lane_blocks256 = (spec->n_lanes + 255) / 256;
   const uint32_t doc_blocks = (args->n_docs + 255) / 256;
   switch (stage) {
     case 0:
@@ -1018,7 +1139,7 @@ extern "C" int dtk_launch_spec(const DtkTableDev *tab, const DtkWalkArgs *args, 
                            tr, *args, *spec, tab->epsilon, tab->unknown, tab->identity);
       });
     case 1:
-      hipLaunchKernelGGL(k_spec_plan, dim3(doc_blocks), dim3(256), 0, s, *args, *spec);
+      hipLaunchKernelGGL(k_spec_link, dim3(lane_blocks256), dim3(256), 0, s, *spec);
       return (int)hipGetLastError();
     case 2:
       return with_trans(tab, [&](auto tr, auto is_matrix) {
@@ -1027,10 +1148,19 @@ extern "C" int dtk_launch_spec(const DtkTableDev *tab, const DtkWalkArgs *args, 
                            tr, *args, *spec, tab->epsilon, tab->unknown, tab->identity);
       });
     case 3:
-      hipLaunchKernelGGL(k_spec_check, dim3(doc_blocks), dim3(256), 0, s, *args, *spec, cmp_mask, redo_out, n_bad);
+      hipLaunchKernelGGL(k_spec_verify, dim3(lane_blocks256), dim3(256), 0, s, *args, *spec, cmp_mask);
       return (int)hipGetLastError();
     case 4:
+      hipLaunchKernelGGL(k_spec_fix, dim3(doc_blocks), dim3(256), 0, s, *args, *spec, redo_out, n_bad);
+      return (int)hipGetLastError();
+    case 5:
       hipLaunchKernelGGL(k_spec_clear, dim3(args->n_docs), dim3(WAVE), 0, s, *args, *spec);
+      return (int)hipGetLastError();
+    case 6:
+      hipLaunchKernelGGL(k_spec_plan, dim3(doc_blocks), dim3(256), 0, s, *args, *spec);
+      return (int)hipGetLastError();
+    case 7:
+      hipLaunchKernelGGL(k_spec_check, dim3(doc_blocks), dim3(256), 0, s, *args, *spec, cmp_mask, redo_out, n_bad);
       return (int)hipGetLastError();
   }
   return -1;
@@ -1046,8 +1176,10 @@ extern "C" int dtk_launch_compact(const DtkCompactArgs *args, int pass, void *st
   return (int)hipGetLastError();
 }
 
-extern "C" int dtk_launch_scan3(uint64_t *a, uint64_t *b, uint64_t *c, uint32_t n_docs, uint64_t *totals,
+extern "C" int dtk_launch_scan3(const uint64_t *ca, const uint64_t *cb, const uint64_t *cc, uint64_t *a,
+                                uint64_t *b, uint64_t *c, uint32_t n_docs, uint64_t *totals,
                                 const uint32_t *status, void *stream) {
-  hipLaunchKernelGGL(k_scan3, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, b, c, n_docs, totals, status);
+  hipLaunchKernelGGL(k_scan3, dim3(1), dim3(1024), 0, (hipStream_t)stream, ca, cb, cc, a, b, c, n_docs, totals,
+                     status);
   return (int)hipGetLastError();
 }

@@ -303,7 +303,7 @@ class Batch:
     def set_profiling(self, enable=True):
         check(lib().dtk_batch_set_profiling(self._h, int(bool(enable))), "dtk_batch_set_profiling")
 
-    STAGES = ("memset", "symbolize", "walk", "compact1", "scan", "compact2")
+    STAGES = ("clear", "symbolize", "walk", "unused", "scan", "compact")
 
     def stage_ms(self):
         """Milliseconds per stage of the last run (needs set_profiling(True))."""

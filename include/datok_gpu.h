@@ -58,7 +58,8 @@ enum {
   DTK_ST_BAD_MODEL = 4,       /* walk left the table */
   DTK_ST_IRREGULAR = 8,       /* >2 sentence ends at one cursor position, or a text end
                                  revisited (double array + in-document EOT backtrack) */
-  DTK_ST_STEP_LIMIT = 16      /* safety cap on lookups hit */
+  DTK_ST_STEP_LIMIT = 16,     /* safety cap on lookups hit */
+  DTK_ST_INTERNAL = 32        /* internal consistency check failed (a bug; never expected) */
 };
 
 typedef struct dtk_model dtk_model;
@@ -126,8 +127,8 @@ void *dtk_batch_stream(dtk_batch *b); /* hipStream_t, for event timing by the ca
 /* Optional per-stage timing with HIP events recorded on the batch's stream
  * around each kernel of dtk_batch_run (no host synchronisation is added).
  * dtk_batch_stage_ms() synchronises and returns the milliseconds of the last
- * run: [0] memset [1] symbolise [2] walk [3] compact pass 1 [4] scan
- * [5] compact pass 2. */
+ * run: [0] clears [1] symbolise [2] walk (start records, link, chunk walk,
+ * verify, fix) [3] unused [4] scan [5] compaction. */
 int dtk_batch_set_profiling(dtk_batch *b, int enable);
 int dtk_batch_stage_ms(dtk_batch *b, float ms[6]);
 

@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-for c in 0 64 128 256 512 1024; do
+for c in ${CHUNKS:-0 64 128 256 512}; do
   python bench.py --chunk $c --steps 30 --warmup 3 --no-cpu-baseline --parity-docs 64 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
