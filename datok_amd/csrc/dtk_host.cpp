@@ -416,7 +416,10 @@ struct dtk_batch {
   uint64_t total = 0;
   // intermediates
   uint16_t *d_sym = nullptr;
-  uint8_t *d_evA = nullptr, *d_evB = nullptr;  // closing / opening event bytes
+  uint8_t *d_ev = nullptr;                     // both event arrays, cleared by one memset
+  uint8_t *d_evA = nullptr, *d_evB = nullptr;  // closing / opening event bytes (carved per run)
+  uint8_t *d_acc = nullptr;                    // per-document accumulators + totals (one memset)
+  uint64_t acc_bytes = 0;
   uint32_t *d_tlen = nullptr;                  // token lengths at their end positions
   uint32_t *d_status = nullptr;
   // speculative chunk lanes
@@ -427,6 +430,7 @@ struct dtk_batch {
   bool plan_valid = false;
   uint32_t n_lanes = 0, lane_cap = 0;
   uint32_t *d_lane_doc = nullptr, *d_chunk_off = nullptr, *d_redo = nullptr;
+  uint32_t *d_blk_doc = nullptr;     // document of the first byte of every 4 KiB input block
   uint32_t *d_first_bad = nullptr, *d_fail_lane = nullptr;
   DtkLaneCount *d_lane_cnt = nullptr;
   DtkLaneState *d_lane_start = nullptr, *d_lane_end = nullptr;
@@ -502,21 +506,18 @@ extern "C" int dtk_batch_create(uint64_t max_bytes, uint32_t max_docs, dtk_batch
   B_TRY(hipMalloc((void **)&b->d_text_own, max_bytes + pad));
   B_TRY(hipMalloc((void **)&b->d_off_own, ((uint64_t)max_docs + 1) * 8));
   B_TRY(hipMalloc((void **)&b->d_sym, (max_bytes + pad) * 2));
-  B_TRY(hipMalloc((void **)&b->d_evA, max_bytes + max_docs + pad));
-  B_TRY(hipMalloc((void **)&b->d_evB, max_bytes + max_docs + pad));
+  B_TRY(hipMalloc((void **)&b->d_ev, 2 * (max_bytes + max_docs + pad)));
+  b->acc_bytes = 64 + 3 * ((uint64_t)max_docs + 1) * 8 + 3 * (uint64_t)max_docs * 4 + 64;
+  B_TRY(hipMalloc((void **)&b->d_acc, b->acc_bytes));
   B_TRY(hipMalloc((void **)&b->d_tlen, (max_bytes + max_docs + pad) * 4));
   B_TRY(hipMalloc((void **)&b->d_redo, (uint64_t)max_docs * 4));
-  B_TRY(hipMalloc((void **)&b->d_first_bad, (uint64_t)max_docs * 4));
-  B_TRY(hipMalloc((void **)&b->d_fail_lane, (uint64_t)max_docs * 4));
+  B_TRY(hipMalloc((void **)&b->d_blk_doc, (max_bytes / DTK_SYM_BLOCK_BYTES + 3) * 4));
+
   B_TRY(hipMalloc((void **)&b->d_chunk_off, ((uint64_t)max_docs + 1) * 4));
-  B_TRY(hipMalloc((void **)&b->d_status, (uint64_t)max_docs * 4));
   B_TRY(hipMalloc((void **)&b->d_tok_off, ((uint64_t)max_docs + 1) * 8));
   B_TRY(hipMalloc((void **)&b->d_sent_off, ((uint64_t)max_docs + 1) * 8));
   B_TRY(hipMalloc((void **)&b->d_text_off, ((uint64_t)max_docs + 1) * 8));
-  B_TRY(hipMalloc((void **)&b->d_tok_cnt, ((uint64_t)max_docs + 1) * 8));
-  B_TRY(hipMalloc((void **)&b->d_sent_cnt, ((uint64_t)max_docs + 1) * 8));
-  B_TRY(hipMalloc((void **)&b->d_text_cnt, ((uint64_t)max_docs + 1) * 8));
-  B_TRY(hipMalloc((void **)&b->d_totals, 8 * 8));
+
   B_TRY(hipHostMalloc((void **)&b->h_totals, 8 * 8, hipHostMallocDefault));
 #undef B_TRY
   // typical German: 0.18 tokens and 0.06 sentence ints per byte; grown on demand
@@ -530,11 +531,10 @@ extern "C" int dtk_batch_create(uint64_t max_bytes, uint32_t max_docs, dtk_batch
 extern "C" void dtk_batch_free(dtk_batch *b) {
   if (!b) return;
   if (b->stream) (void)hipStreamSynchronize(b->stream);
-  void *ptrs[] = {b->d_text_own, b->d_off_own, b->d_sym, b->d_evA, b->d_evB, b->d_tlen, b->d_redo, b->d_chunk_off,
+  void *ptrs[] = {b->d_text_own, b->d_off_own, b->d_sym, b->d_ev, b->d_acc, b->d_tlen, b->d_redo, b->d_chunk_off, b->d_blk_doc,
                   b->d_lane_doc, b->d_lane_cnt, b->d_lane_start, b->d_lane_end, b->d_lane_plan,
-                  b->d_first_bad, b->d_fail_lane, b->d_tok_cnt, b->d_sent_cnt, b->d_text_cnt,
-                  b->d_status, b->d_tok_off,
-                  b->d_sent_off, b->d_text_off, b->d_totals, b->d_rstart, b->d_rend, b->d_sent,
+                  b->d_tok_off,
+                  b->d_sent_off, b->d_text_off, b->d_rstart, b->d_rend, b->d_sent,
                   b->d_bstart, b->d_bend, b->d_ttok, b->d_tsent};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
@@ -603,6 +603,20 @@ extern "C" int dtk_batch_set_chunking(dtk_batch *b, uint32_t chunk_bytes, uint32
 // Splits the documents into chunk lanes (host side of the speculative walk).
 static int plan_lanes(dtk_batch *b) {
   if (b->plan_valid) return DTK_OK;
+  {
+    // document of the first byte of every symbolise block (+ one entry behind the end)
+    const uint64_t nblk = (b->total + DTK_SYM_BLOCK_BYTES - 1) / DTK_SYM_BLOCK_BYTES;
+    std::vector<uint32_t> blk((size_t)nblk + 2);
+    uint32_t d = 0;
+    for (uint64_t i = 0; i <= nblk; i++) {
+      const uint64_t g = i * DTK_SYM_BLOCK_BYTES;
+      while (d + 1 < b->n_docs && b->h_doc_off[d + 1] <= g) d++;
+      blk[i] = d;
+    }
+    blk[nblk + 1] = b->n_docs - 1;
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipMemcpy(b->d_blk_doc, blk.data(), blk.size() * 4, hipMemcpyHostToDevice));
+  }
   uint32_t C = b->cfg_chunk;
   if (C == 0xFFFFFFFFu) {
     // enough lanes to give every SIMD of the chip a few waves, but chunks no shorter than
@@ -701,20 +715,27 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
   const bool prof = b->profiling;
 #define STAGE(i) do { if (prof) HIP_TRY(hipEventRecord(b->ev[i], s)); } while (0)
   STAGE(0);
-  HIP_TRY(hipMemsetAsync(b->d_evA, 0, b->total + b->n_docs, s));
-  HIP_TRY(hipMemsetAsync(b->d_evB, 0, b->total + b->n_docs, s));
-  HIP_TRY(hipMemsetAsync(b->d_totals, 0, 8 * 8, s));
-  if (b->chunk != 0) {
-    // per-document accumulators of the check pass
-    HIP_TRY(hipMemsetAsync(b->d_status, 0, (size_t)b->n_docs * 4, s));
-    HIP_TRY(hipMemsetAsync(b->d_tok_cnt, 0, ((size_t)b->n_docs + 1) * 8, s));
-    HIP_TRY(hipMemsetAsync(b->d_sent_cnt, 0, ((size_t)b->n_docs + 1) * 8, s));
-    HIP_TRY(hipMemsetAsync(b->d_text_cnt, 0, ((size_t)b->n_docs + 1) * 8, s));
-    HIP_TRY(hipMemsetAsync(b->d_first_bad, 0xFF, (size_t)b->n_docs * 4, s));
-    HIP_TRY(hipMemsetAsync(b->d_fail_lane, 0xFF, (size_t)b->n_docs * 4, s));
+  {
+    // carve the accumulator block for this run's document count: totals, counts, status,
+    // check words -- all cleared by one memset; the two event arrays by a second one
+    const size_t nd = b->n_docs;
+    uint8_t *q = b->d_acc;
+    b->d_totals = (uint64_t *)q; q += 64;
+    b->d_tok_cnt = (uint64_t *)q; q += (nd + 1) * 8;
+    b->d_sent_cnt = (uint64_t *)q; q += (nd + 1) * 8;
+    b->d_text_cnt = (uint64_t *)q; q += (nd + 1) * 8;
+    b->d_status = (uint32_t *)q; q += nd * 4;
+    b->d_first_bad = (uint32_t *)q; q += nd * 4;
+    b->d_fail_lane = (uint32_t *)q; q += nd * 4;
+    HIP_TRY(hipMemsetAsync(b->d_acc, 0, (size_t)(q - b->d_acc), s));
+    const size_t ev_bytes = (b->total + nd + 255) & ~(size_t)255;
+    b->d_evA = b->d_ev;
+    b->d_evB = b->d_ev + ev_bytes;
+    HIP_TRY(hipMemsetAsync(b->d_ev, 0, 2 * ev_bytes, s));
   }
   STAGE(1);
-  if (dtk_launch_symbolize(b->d_text, b->d_off, b->n_docs, b->total, &m->sig, b->d_sym, s))
+  if (dtk_launch_symbolize(b->d_text, b->d_off, b->n_docs, b->total, &m->sig, b->d_sym,
+                           b->d_text == b->d_text_own, b->d_blk_doc, s))
     return hip_fail(hipGetLastError(), "symbolize");
   STAGE(2);
   DtkWalkArgs w = walk_args(b);

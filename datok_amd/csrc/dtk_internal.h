@@ -154,7 +154,9 @@ extern "C" {
 #endif
 // launchers (dtk_kernels.hip); stream is a hipStream_t
 int dtk_launch_symbolize(const uint8_t *text, const uint64_t *doc_off, uint32_t n_docs,
-                         uint64_t total, const struct DtkSigmaDev *sig, uint16_t *sym, void *stream);
+                         uint64_t total, const struct DtkSigmaDev *sig, uint16_t *sym, int padded,
+                         const uint32_t *blk_doc, void *stream);
+#define DTK_SYM_BLOCK_BYTES 4096u  // input bytes per symbolise block (blk_doc granularity)
 int dtk_launch_walk(const struct DtkTableDev *tab, const struct DtkWalkArgs *args, void *stream);
 int dtk_launch_spec(const struct DtkTableDev *tab, const struct DtkWalkArgs *args,
                     const struct DtkSpecArgs *spec, int stage, uint32_t cmp_mask, uint32_t *redo_out,

@@ -55,127 +55,196 @@ __device__ __forceinline__ uint32_t go_decode(uint32_t b0, uint32_t b1, uint32_t
 
 // ---------------------------------------------------------------- symbolise
 //
-// One thread per 16 input bytes: one 16-byte load plus the 4 bytes either side
-// (3 bytes of look-back decide whether a continuation byte is covered by an
-// earlier valid sequence, 3 bytes of look-ahead complete a sequence), two
-// 16-byte stores of symbol entries.  Documents never share a rune: look-back
-// and look-ahead stop at the document boundary (reader EOF).
+// One lane per 4 input bytes, a 256-thread block per 4 KiB.  Each lane decodes
+// its four positions "as if a rune started there" with Go's DecodeRune rules
+// (straight-line selects, no divergence), looks the rune up (runes < 256 through a
+// 256-entry table in LDS, the few others by binary search) and decides whether the
+// position really starts a rune from the widths of the three positions before it.
+// The neighbouring dwords come from the adjacent lanes by shuffle.  Documents
+// never share a rune: look-back and look-ahead stop at the document boundary
+// (reader EOF, matrix.go:394-399).
 
-#define SYM_PER_THREAD 16
+#define SYM_BLOCK_BYTES DTK_SYM_BLOCK_BYTES
 
+// width Go's DecodeRune reports at a position (b0 first byte, `avail` bytes left in the
+// document).  Integer predicates on purpose: bool && chains become branches.
+__device__ __forceinline__ uint32_t go_width(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, uint32_t avail) {
+  const uint32_t c1 = (b1 & 0xC0u) == 0x80u, c2 = (b2 & 0xC0u) == 0x80u, c3 = (b3 & 0xC0u) == 0x80u;
+  const uint32_t two = (uint32_t)(b0 - 0xC2u < 0x1Eu) & (uint32_t)(avail >= 2u) & c1;  // C2..DF
+  const uint32_t lo3 = b0 == 0xE0u ? 0xA0u : 0x80u, hi3 = b0 == 0xEDu ? 0x9Fu : 0xBFu;
+  const uint32_t three = (uint32_t)((b0 & 0xF0u) == 0xE0u) & (uint32_t)(avail >= 3u) & (uint32_t)(b1 >= lo3) &
+                         (uint32_t)(b1 <= hi3) & c2;
+  const uint32_t lo4 = b0 == 0xF0u ? 0x90u : 0x80u, hi4 = b0 == 0xF4u ? 0x8Fu : 0xBFu;
+  const uint32_t four = (uint32_t)(b0 - 0xF0u <= 4u) & (uint32_t)(avail >= 4u) & (uint32_t)(b1 >= lo4) &
+                        (uint32_t)(b1 <= hi4) & c2 & c3;
+  return 1u + two + 2u * three + 3u * four;  // mutually exclusive
+}
+
+__device__ __forceinline__ uint32_t doc_of(const uint64_t *__restrict__ doc_off, uint32_t lo, uint32_t hi,
+                                           uint64_t g) {
+  // largest d in [lo, hi) with doc_off[d] <= g   (invariant: doc_off[lo] <= g < doc_off[hi])
+  while (hi - lo > 1) {
+    const uint32_t mid = lo + ((hi - lo) >> 1);
+    if (doc_off[mid] <= g) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+template <bool ALIGNED4>
 __global__ __launch_bounds__(256) void k_symbolize(const uint8_t *__restrict__ text,
                                                    const uint64_t *__restrict__ doc_off,
                                                    uint32_t n_docs, uint64_t total, DtkSigmaDev sig,
-                                                   uint16_t *__restrict__ sym) {
-  const uint64_t g0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * SYM_PER_THREAD;
-  if (g0 >= total) return;
+                                                   uint16_t *__restrict__ sym,
+                                                   const uint32_t *__restrict__ blk_doc) {
+  __shared__ uint16_t lut[256];
+  __shared__ uint32_t s_pack[4];     // decode summary of each wave's last lane, for the next wave
+  __shared__ uint32_t s_runes[256];  // sigma map (runes >= 256 are rare but a global-memory binary
+  __shared__ uint16_t s_syms[256];   // search would stall the whole wave for one lane)
+  const uint32_t tid = threadIdx.x, wv = tid >> 6, ln = tid & 63u;
+  const bool sig_lds = sig.n_runes <= 256u;
+  if (sig_lds && tid < sig.n_runes) { s_runes[tid] = sig.runes[tid]; s_syms[tid] = sig.syms[tid]; }
+  // symbol | class for every rune < 256 (matrix.go:421-426)
+  lut[tid] = (uint16_t)((sig.ascii[tid] & DTK_SYM_MASK) | (tid == DTK_EOT ? (1u << DTK_SYM_CLS_SHIFT) : 0u));
+  const uint64_t block_start = (uint64_t)blockIdx.x * SYM_BLOCK_BYTES;
+  const uint64_t block_last = min(block_start + SYM_BLOCK_BYTES, total) - 1;
+  __syncthreads();
+  // documents that can own bytes of this block: host-computed (document of each block's
+  // first byte), so no lane walks the offset table from scratch
+  const uint32_t d_lo = blk_doc[blockIdx.x];
+  const uint32_t d_hi = min(blk_doc[blockIdx.x + 1], n_docs - 1);
+  (void)block_last;
 
-  // window of 24 bytes: w[k] = text[g0 - 4 + k]
-  uint32_t wq[6];
-  const bool aligned = (((uintptr_t)text) & 15u) == 0;
-  if (aligned && g0 + 16 <= total) {
-    const uint4 v = *reinterpret_cast<const uint4 *>(text + g0);
-    wq[1] = v.x; wq[2] = v.y; wq[3] = v.z; wq[4] = v.w;
-  } else {
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      uint32_t x = 0;
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        uint64_t g = g0 + q * 4 + k;
-        if (g < total) x |= (uint32_t)text[g] << (8 * k);
-      }
-      wq[1 + q] = x;
+  auto load4 = [&](uint64_t g) -> uint32_t {  // bytes g..g+3, zero behind the end
+    if (ALIGNED4) {
+      // the text buffer is padded: a dword that straddles the end is readable, mask it
+      const uint32_t x = *reinterpret_cast<const uint32_t *>(text + g);
+      const uint64_t left = total - g;
+      return left >= 4 ? x : (x & ((1u << (8 * (uint32_t)left)) - 1u));
     }
-  }
-  {
     uint32_t x = 0;
-    if (g0 >= 4) {
-#pragma unroll
-      for (int k = 0; k < 4; k++) x |= (uint32_t)text[g0 - 4 + k] << (8 * k);
-    }
-    wq[0] = x;
-    x = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      uint64_t g = g0 + 16 + k;
-      if (g < total) x |= (uint32_t)text[g] << (8 * k);
-    }
-    wq[5] = x;
-  }
-#define WB(k) ((wq[(k) >> 2] >> (8 * ((k)&3))) & 0xFFu)
+    for (int k = 0; k < 4; k++)
+      if (g + k < total) x |= (uint32_t)text[g + k] << (8 * k);
+    return x;
+  };
 
-  // document containing g0: largest d with doc_off[d] <= g0
-  uint32_t lo = 0, hi = n_docs;  // invariant: doc_off[lo] <= g0, doc_off[hi] > g0
-  while (hi - lo > 1) {
-    uint32_t mid = lo + ((hi - lo) >> 1);
-    if (doc_off[mid] <= g0) lo = mid; else hi = mid;
-  }
-  uint32_t d = lo;
-  uint64_t dstart = doc_off[d], dend = doc_off[d + 1];
+#pragma unroll 1
+  for (uint32_t it = 0; it < SYM_BLOCK_BYTES / 1024u; it++) {
+    const uint64_t g0 = block_start + it * 1024u + tid * 4u;
+    const bool live = g0 < total;
+    const uint32_t w = live ? load4(g0) : 0u;
+    uint32_t wn = __shfl_down(w, 1);  // the next dword sits in the next lane of the wave
+    if (ln == 63u) wn = (live && g0 + 4 < total) ? load4(g0 + 4) : 0u;
 
-  uint32_t outw[8];
-#pragma unroll
-  for (int j = 0; j < SYM_PER_THREAD; j++) {
-    const uint64_t g = g0 + j;
-    uint32_t entry = 0;
-    if (g < total) {
-      while (g >= dend) { d++; dstart = dend; dend = doc_off[d + 1]; }
-      const uint64_t left = dend - g;
-      const uint32_t avail = left > 4 ? 4u : (uint32_t)left;
-      uint32_t rune;
-      const uint32_t b0 = WB(4 + j);
-      const uint32_t width = go_decode(b0, WB(5 + j), WB(6 + j), WB(7 + j), avail, rune);
-      // does this byte start a rune?  a non-continuation byte always does; a
-      // continuation byte does unless the nearest non-continuation byte within
-      // the previous 3 (same document) begins a valid sequence that covers it.
-      uint32_t start = 1;
-      if ((b0 & 0xC0u) == 0x80u) {
-        const uint64_t back = g - dstart;
-#pragma unroll
-        for (int k = 1; k <= 3; k++) {
-          if (start == 1 && (uint64_t)k <= back) {
-            const uint32_t l0 = WB(4 + j - k);
-            if ((l0 & 0xC0u) != 0x80u) {
-              uint32_t r2;
-              const uint64_t left2 = dend - (g - k);
-              const uint32_t w2 = go_decode(l0, WB(5 + j - k), WB(6 + j - k), WB(7 + j - k),
-                                            left2 > 4 ? 4u : (uint32_t)left2, r2);
-              start = (w2 > (uint32_t)k) ? 0u : 2u;  // 2: decided "is a start", stop looking
-            }
+    uint32_t b[7];  // b[0..3] own bytes, b[4..6] look-ahead
+    b[0] = w & 0xFFu; b[1] = (w >> 8) & 0xFFu; b[2] = (w >> 16) & 0xFFu; b[3] = w >> 24;
+    b[4] = wn & 0xFFu; b[5] = (wn >> 8) & 0xFFu; b[6] = (wn >> 16) & 0xFFu;
+
+    // per position: bytes left in its document / bytes behind it in its document,
+    // saturated at 8.  Far from a document boundary (the usual case) both are 8.
+    uint32_t left[4] = {8u, 8u, 8u, 8u}, back[4] = {8u, 8u, 8u, 8u};
+    if (live) {
+      uint32_t d = d_lo == d_hi ? d_lo : doc_of(doc_off, d_lo, d_hi + 1, g0);
+      uint64_t dstart = doc_off[d], dend = doc_off[d + 1];
+      if (dend - g0 < 12 || g0 - dstart < 4) {  // a boundary within reach: exact values
+        for (int j = 0; j < 4; j++) {
+          const uint64_t g = g0 + j;
+          if (g < total) {
+            while (g >= dend) { d++; dstart = dend; dend = doc_off[d + 1]; }  // next document(s)
+            const uint64_t l = dend - g, bk = g - dstart;
+            left[j] = l > 8 ? 8u : (uint32_t)l;
+            back[j] = bk > 8 ? 8u : (uint32_t)bk;
+          } else {
+            left[j] = 0; back[j] = 0;
           }
         }
-        start = start ? 1u : 0u;
       }
-      uint32_t a, cls;
-      if (rune < 256u) {  // matrix.go:421-426
-        a = sig.ascii[rune];
-        cls = rune == DTK_EOT ? 1u : 0u;
+    }
+    uint32_t pk = 0, width[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      width[j] = go_width(b[j], b[j + 1], b[j + 2], b[j + 3], left[j]);
+      pk |= (width[j] - 1u) << (2 * j);
+      pk |= ((b[j] & 0xC0u) != 0x80u ? 1u : 0u) << (8 + j);
+    }
+    // the same summary of the 4 positions before mine
+    uint32_t pp = __shfl_up(pk, 1);
+    if (ln == 63u) s_pack[wv] = pk;
+    __syncthreads();
+    if (ln == 0) {
+      if (wv > 0) {
+        pp = s_pack[wv - 1];
+      } else if (live && g0 >= 4) {  // first lane of the block: decode the previous dword myself
+        const uint32_t wp = load4(g0 - 4);
+        const uint32_t bb[7] = {wp & 0xFFu, (wp >> 8) & 0xFFu, (wp >> 16) & 0xFFu, wp >> 24, b[0], b[1], b[2]};
+        // those positions are only consulted when they lie in my document (k <= back),
+        // where "bytes left" is mine + 4
+        const uint32_t l0 = left[0] + 4u > 8u ? 8u : left[0] + 4u;
+        pp = 0;
+        for (int j = 0; j < 4; j++) {
+          const uint32_t wd = go_width(bb[j], bb[j + 1], bb[j + 2], bb[j + 3], l0 > (uint32_t)j ? l0 - j : 0u);
+          pp |= (wd - 1u) << (2 * j);
+          pp |= ((bb[j] & 0xC0u) != 0x80u ? 1u : 0u) << (8 + j);
+        }
+      } else {
+        pp = 0;
+      }
+    }
+    __syncthreads();
+    if (!live) continue;
+
+    const uint32_t both = pp | (pk << 16);  // positions -4..-1 in the low half, 0..3 in the high half
+    uint32_t out[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t b0 = b[j], b1 = b[j + 1], b2 = b[j + 2], b3 = b[j + 3];
+      const uint32_t wd = width[j];
+      // rune value for the decoded width (U+FFFD for an invalid byte)
+      const uint32_t r2 = ((b0 & 0x1Fu) << 6) | (b1 & 0x3Fu);
+      const uint32_t r3 = ((b0 & 0x0Fu) << 12) | ((b1 & 0x3Fu) << 6) | (b2 & 0x3Fu);
+      const uint32_t r4 = ((b0 & 0x07u) << 18) | ((b1 & 0x3Fu) << 12) | ((b2 & 0x3Fu) << 6) | (b3 & 0x3Fu);
+      const uint32_t r1 = b0 < 0x80u ? b0 : 0xFFFDu;
+      const uint32_t rune = wd == 1 ? r1 : (wd == 2 ? r2 : (wd == 3 ? r3 : r4));
+      // does this byte start a rune?  a non-continuation byte always does; a
+      // continuation byte does unless the nearest non-continuation byte within the
+      // previous 3 (same document) begins a valid sequence that reaches it.
+      uint32_t start = 1, open = (b0 & 0xC0u) == 0x80u;  // open: still looking
+#pragma unroll
+      for (int k = 1; k <= 3; k++) {
+        const int q = j - k;  // position index: >= 0 mine, < 0 previous lane's
+        const uint32_t sh_w = q >= 0 ? 16 + 2 * q : 2 * (q + 4);
+        const uint32_t sh_n = q >= 0 ? 24 + q : 8 + (q + 4);
+        const uint32_t w2 = ((both >> sh_w) & 3u) + 1u;
+        const uint32_t noncont = (both >> sh_n) & 1u;
+        const uint32_t inside = (uint32_t)k <= back[j];
+        const uint32_t cand = open & inside & noncont;
+        start = cand ? (uint32_t)(w2 <= (uint32_t)k) : start;
+        open = open & inside & (noncont ^ 1u);
+      }
+      uint32_t a_cls;
+      if (rune < 256u) {
+        a_cls = lut[rune];
       } else {  // matrix.go:427-435: a, ok = sigma[char]; !ok -> identity
         int l = 0, h = (int)sig.n_runes - 1;
-        a = sig.identity;
-        cls = 3u;
+        a_cls = (sig.identity & DTK_SYM_MASK) | (3u << DTK_SYM_CLS_SHIFT);
         while (l <= h) {
-          int m = (l + h) >> 1;
-          uint32_t r = sig.runes[m];
-          if (r == rune) { a = sig.syms[m]; cls = 2u; break; }
+          const int m = (l + h) >> 1;
+          const uint32_t r = sig_lds ? s_runes[m] : sig.runes[m];
+          if (r == rune) {
+            a_cls = ((sig_lds ? (uint32_t)s_syms[m] : (uint32_t)sig.syms[m]) & DTK_SYM_MASK) |
+                    (2u << DTK_SYM_CLS_SHIFT);
+            break;
+          }
           if (r < rune) l = m + 1; else h = m - 1;
         }
       }
-      entry = (a & DTK_SYM_MASK) | ((width - 1) << DTK_SYM_W_SHIFT) | (cls << DTK_SYM_CLS_SHIFT) |
-              (start ? DTK_SYM_START : 0u);
+      out[j] = a_cls | ((wd - 1) << DTK_SYM_W_SHIFT) | (start ? DTK_SYM_START : 0u);
     }
-    if (j & 1) outw[j >> 1] |= entry << 16; else outw[j >> 1] = entry;
-  }
-#undef WB
-  if (g0 + 16 <= total && ((((uintptr_t)sym) & 15u) == 0)) {
-    uint4 *o = reinterpret_cast<uint4 *>(sym + g0);
-    o[0] = make_uint4(outw[0], outw[1], outw[2], outw[3]);
-    o[1] = make_uint4(outw[4], outw[5], outw[6], outw[7]);
-  } else {
-#pragma unroll
-    for (int j = 0; j < SYM_PER_THREAD; j++)
-      if (g0 + j < total) sym[g0 + j] = (uint16_t)(outw[j >> 1] >> (16 * (j & 1)));
+    if (g0 + 4 <= total) {
+      *reinterpret_cast<uint2 *>(sym + g0) = make_uint2(out[0] | (out[1] << 16), out[2] | (out[3] << 16));
+    } else {
+      for (int j = 0; j < 4; j++)
+        if (g0 + j < total) sym[g0 + j] = (uint16_t)out[j];
+    }
   }
 }
 
@@ -630,7 +699,7 @@ __global__ __launch_bounds__(256) void k_spec_plan(DtkWalkArgs A, DtkSpecArgs S)
 __device__ __forceinline__ DtkLanePlan plan_of(const DtkSpecArgs &S, uint32_t L, uint32_t d) {
   if (S.redo_from) return S.lane_plan[L];
   const uint32_t L0 = S.chunk_off[d], L1 = S.chunk_off[d + 1];
-  const uint32_t k = L - L0, fb = S.first_bad[d];
+  const uint32_t k = L - L0, fb = ~S.first_bad[d];
   DtkLanePlan pl;
   pl.pad = 0;
   if (k < fb) {
@@ -649,8 +718,9 @@ __device__ __forceinline__ DtkLanePlan plan_of(const DtkSpecArgs &S, uint32_t L,
 }
 
 // One thread per lane: is my successor's record present and not before mine?
-// first_bad[d] (preset to 0xFFFFFFFF) becomes the first chunk index without such a
-// successor; the last lane of a document never has one.
+// first_bad[d] becomes the first chunk index without such a successor (stored
+// bit-inverted so that a zero fill means "none yet"); the last lane of a document
+// never has one.
 __global__ __launch_bounds__(256) void k_spec_link(DtkSpecArgs S) {
   const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
   if (L >= S.n_lanes) return;
@@ -661,7 +731,7 @@ __global__ __launch_bounds__(256) void k_spec_link(DtkSpecArgs S) {
     const uint32_t np = S.lane_start[L + 1].p, mp = S.lane_start[L].p;
     linked = np != 0xFFFFFFFFu && mp != 0xFFFFFFFFu && np >= mp;
   }
-  if (!linked) atomicMin(&S.first_bad[d], L - L0);
+  if (!linked) atomicMax(&S.first_bad[d], ~(L - L0));  // stored inverted: zero fill = none
 }
 
 template <typename TRANS, bool IS_MATRIX>
@@ -698,16 +768,16 @@ __global__ __launch_bounds__(WAVE) void k_spec_walk(TRANS tr, DtkWalkArgs A, Dtk
 
 // One thread per lane: did I arrive exactly at my successor's record (position,
 // state, flags)?  Lanes that did add their counts / status to the document; the
-// first lane that did not is recorded in fail_lane[d] (preset to 0xFFFFFFFF).
+// first lane that did not is recorded (bit-inverted, zero = none) in fail_lane[d].
 __global__ __launch_bounds__(256) void k_spec_verify(DtkWalkArgs A, DtkSpecArgs S, uint32_t cmp_mask) {
   const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
   if (L >= S.n_lanes) return;
   const uint32_t d = S.lane_doc[L];
   const uint32_t L0 = S.chunk_off[d];
-  const uint32_t k = L - L0, fb = S.first_bad[d];
+  const uint32_t k = L - L0, fb = ~S.first_bad[d];
   if (k > fb) {
     // a lane behind the chain: legitimate only if the chain ran to EOF and I found no sync point
-    if (S.lane_start[L].p != 0xFFFFFFFFu) atomicMin(&S.fail_lane[d], L0 + fb);
+    if (S.lane_start[L].p != 0xFFFFFFFFu) atomicMax(&S.fail_lane[d], ~(L0 + fb));
     return;
   }
   const DtkLaneState en = S.lane_end[L];
@@ -719,7 +789,7 @@ __global__ __launch_bounds__(256) void k_spec_verify(DtkWalkArgs A, DtkSpecArgs 
   } else {
     good = en.p == 0xFFFFFFFFu && !(en.flags & LANE_F_IDLE);  // the chain's last lane must reach EOF
   }
-  if (!good) { atomicMin(&S.fail_lane[d], L); return; }
+  if (!good) { atomicMax(&S.fail_lane[d], ~L); return; }
   const DtkLaneCount c = S.lane_cnt[L];
   if (c.tok) atomicAdd((unsigned long long *)&A.tok_cnt[d], (unsigned long long)c.tok);
   if (c.sent) atomicAdd((unsigned long long *)&A.sent_cnt[d], (unsigned long long)c.sent);
@@ -748,7 +818,7 @@ __global__ __launch_bounds__(256) void k_spec_fix(DtkWalkArgs A, DtkSpecArgs S, 
                                                   uint32_t *n_bad) {
   const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d >= A.n_docs) return;
-  const uint32_t bad = S.fail_lane[d];
+  const uint32_t bad = ~S.fail_lane[d];
   if (bad == 0xFFFFFFFFu) { redo_out[d] = 0xFFFFFFFFu; return; }
   mark_redo(S, d, bad, redo_out, n_bad);
 }
@@ -1084,12 +1154,18 @@ __global__ __launch_bounds__(1024) void k_scan3(const uint64_t *ca, const uint64
 // ---------------------------------------------------------------- launchers
 
 extern "C" int dtk_launch_symbolize(const uint8_t *text, const uint64_t *doc_off, uint32_t n_docs,
-                                    uint64_t total, const DtkSigmaDev *sig, uint16_t *sym, void *stream) {
+                                    uint64_t total, const DtkSigmaDev *sig, uint16_t *sym, int padded,
+                                    const uint32_t *blk_doc, void *stream) {
   if (total == 0 || n_docs == 0) return 0;
-  const uint64_t threads = (total + SYM_PER_THREAD - 1) / SYM_PER_THREAD;
-  const uint32_t blocks = (uint32_t)((threads + 255) / 256);
-  hipLaunchKernelGGL(k_symbolize, dim3(blocks), dim3(256), 0, (hipStream_t)stream, text, doc_off, n_docs,
-                     total, *sig, sym);
+  const uint32_t blocks = (uint32_t)((total + SYM_BLOCK_BYTES - 1) / SYM_BLOCK_BYTES);
+  // ALIGNED4 may read up to 3 bytes past `total`: true for the batch's own (padded) buffer;
+  // a caller-owned device buffer only qualifies when its size is a multiple of 4
+  if ((((uintptr_t)text) & 3u) == 0 && (padded || (total & 3u) == 0))
+    hipLaunchKernelGGL(k_symbolize<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, text, doc_off, n_docs,
+                       total, *sig, sym, blk_doc);
+  else
+    hipLaunchKernelGGL(k_symbolize<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, text, doc_off, n_docs,
+                       total, *sig, sym, blk_doc);
   return (int)hipGetLastError();
 }
 
