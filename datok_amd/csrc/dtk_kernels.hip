@@ -446,97 +446,97 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
 
   // One table lookup per iteration (the reference's loop body, matrix.go:384-635),
   // written as predicates + selects so that the 64 lanes of a wave, which are all
-  // in different phases of their tokens, share one short instruction stream; only
-  // the stores and the rare paths (EOF drain, EOT, hard fail) are branches.
+  // in different phases of their tokens, share one short instruction stream.  Real
+  // branches are kept for the symbol fetch, the two event stores and three rare
+  // paths (EOF drain; hard fail; EOT / window limit / end of chunk).
   bool done = false;
   do {
-    if (newchar) {
-      if (p < len) {
-        const uint32_t i = p + o3, g = i >> 2;
-        if (g != grp) {
-          q_cur = (g == grp + 1u) ? q_next : sq[g];  // else: after a backtrack / at the start
-          q_next = sq[g + 1u];                       // in flight for the next ~4 runes
-          grp = g;
-        }
-        const uint32_t e = (uint32_t)(q_cur >> ((i & 3u) * 16u)) & 0xFFFFu;
-        a = e & DTK_SYM_MASK;
-        w = ((e >> DTK_SYM_W_SHIFT) & 3u) + 1u;
-        const uint32_t cls = (e >> DTK_SYM_CLS_SHIFT) & 3u;
-        hi = max(hi, p + w);             // matrix.go:388-408: runes enter the window once
-        eot = cls == 1u;                 // matrix.go:422
-        ok = cls >= 2u ? cls == 2u : ok; // matrix.go:427: only runes >= 256 write `ok`
-        t0 = t; aux0 = aux;              // matrix.go:437
-        const bool he = tr.has_eps(t0, aux0);  // matrix.go:442-454
-        eps_t = he ? t0 : eps_t; eps_aux = he ? aux0 : eps_aux;
-        eps_p = he ? p : eps_p; eps_rl = he ? rl : eps_rl;
-      } else {
-        // reader at EOF: the drain of matrix.go:650-668 / datok.go:1085-1103
-        t0 = t; aux0 = aux;
-        a = epsilon;
-        newchar = false;
-        if (tr.has_eps(t0, aux0)) {
-          // goto PARSECHARM with a = epsilon
-        } else if (eps_t != 0) {
-          t0 = eps_t; aux0 = eps_aux;
-          eps_t = 0;
-          p = eps_p; rl = eps_rl;
-        } else {
-          done = true;
-        }
-      }
+    if (newchar && p >= len) {
+      // reader at EOF: the drain of matrix.go:650-668 / datok.go:1085-1103
+      const bool he = tr.has_eps(t, aux);          // goto PARSECHARM with a = epsilon
+      const bool bt = !he && eps_t != 0;           // or pop the remembered epsilon state
+      t0 = bt ? eps_t : t; aux0 = bt ? eps_aux : aux;
+      p = bt ? eps_p : p; rl = bt ? eps_rl : rl;
+      eps_t = bt ? 0u : eps_t;
+      a = epsilon;
+      newchar = false;
+      done = !he && !bt;
     }
-    if (!done) {
-      bool nontoken = false;
-      const bool good = tr.step(t0, aux0, a, t, aux, nontoken, st);
-      my_steps++;
+    if (newchar) {
+      const uint32_t i = p + o3, g = i >> 2;
+      if (g != grp) {
+        q_cur = (g == grp + 1u) ? q_next : sq[g];  // else: after a backtrack / at the start
+        q_next = sq[g + 1u];                       // in flight for the next ~4 runes
+        grp = g;
+      }
+      const uint32_t half = (i & 2u) ? (uint32_t)(q_cur >> 32) : (uint32_t)q_cur;
+      const uint32_t e = (i & 1u) ? (half >> 16) : (half & 0xFFFFu);
+      a = e & DTK_SYM_MASK;
+      w = ((e >> DTK_SYM_W_SHIFT) & 3u) + 1u;
+      const uint32_t cls = (e >> DTK_SYM_CLS_SHIFT) & 3u;
+      hi = max(hi, p + w);             // matrix.go:388-408: runes enter the window once
+      eot = cls == 1u;                 // matrix.go:422
+      ok = cls >= 2u ? cls == 2u : ok; // matrix.go:427: only runes >= 256 write `ok`
+      t0 = t; aux0 = aux;              // matrix.go:437
+      const bool he = tr.has_eps(t0, aux0);  // matrix.go:442-454
+      eps_t = he ? t0 : eps_t; eps_aux = he ? aux0 : eps_aux;
+      eps_p = he ? p : eps_p; eps_rl = he ? rl : eps_rl;
+    }
 
-      const bool is_eps = a == epsilon;
-      const bool retry_unknown = !good && !ok && a == identity;              // matrix.go:478-485
-      const bool backtrack = !good && !retry_unknown && !is_eps && eps_t != 0;  // matrix.go:487-497
-      bool hardfail = !good && !retry_unknown && !backtrack;                 // matrix.go:499-552
-      const bool flush_eps = good && is_eps && p > tp;                       // matrix.go:565-572
-      const bool sent_eps = good && is_eps && p <= tp;                       // matrix.go:573-576
-      const bool advance = good && !is_eps;                                  // matrix.go:579-591
+    bool nontoken = false;
+    const bool good = tr.step(t0, aux0, a, t, aux, nontoken, st);  // a finished lane looks up harmlessly
+    const bool act = !done;
+    my_steps += act ? 1u : 0u;
+    const bool is_eps = a == epsilon;
+    const bool succ = act && good, fail = act && !good;
+    const bool retry_unknown = fail && !ok && a == identity;               // matrix.go:478-485
+    const bool backtrack = fail && !retry_unknown && !is_eps && eps_t != 0;   // matrix.go:487-497
+    bool hardfail = fail && !retry_unknown && !backtrack;                  // matrix.go:499-552
+    const bool flush_eps = succ && is_eps && p > tp;                       // matrix.go:565-572
+    const bool sent_eps = succ && is_eps && p <= tp;                       // matrix.go:573-576
+    const bool advance = succ && !is_eps;                                  // matrix.go:579-591
+    const bool eot_now = advance && eot;                                   // matrix.go:593-605
 
-      if (hardfail) {  // rare: drop what is buffered as a token, restart at state 1
+    if (hardfail || my_steps > cap) {  // rare
+      if (hardfail) {  // drop what is buffered as a token, restart at state 1
         if (is_eps) { st |= ST_BAD_MODEL; done = true; hardfail = false; }  // stale-buffer case
         else if (p <= tp) { p += w; rl++; }                                  // matrix.go:515-516
         t = t_start; aux = aux_start;                                        // matrix.go:548
       }
-      const bool flush = flush_eps || hardfail;
-      if (MODE != MODE_START) {
-        if (flush)  // matrix.go:528 / 569
-          sink.template token<IS_MATRIX>(tp, p, rl, sentence_end || text_end || !any_tok);
-        if (sent_eps) sink.sentence(p, has_tok);  // matrix.go:575
-      }
-      any_tok = any_tok || flush;
-      has_tok = has_tok || flush;
-      // consume the rune
-      const bool first = p == tp;
-      p = advance ? p + w : p;
-      rl = advance ? rl + 1u : rl;
-      const bool skip = advance && first && nontoken;  // matrix.go:584-588: leading non-token rune
-      tp = skip ? p : tp;
-      rl = skip ? 0u : rl;
-      const bool eot_now = advance && eot;  // matrix.go:593-605 / datok.go:1019-1030
+      if (my_steps > cap) { st |= ST_STEP_LIMIT; done = true; hardfail = false; }
+    }
+    const bool flush = flush_eps || hardfail;
+    if (MODE != MODE_START) {
+      if (flush)  // matrix.go:528 / 569
+        sink.template token<IS_MATRIX>(tp, p, rl, sentence_end || text_end || !any_tok);
+      if (sent_eps) sink.sentence(p, has_tok);  // matrix.go:575
+    }
+    any_tok = any_tok || flush;
+    has_tok = has_tok || flush;
+    // consume the rune
+    const bool skip = advance && p == tp && nontoken;  // matrix.go:584-588: leading non-token rune
+    p = advance ? p + w : p;
+    rl = skip ? 0u : (advance ? rl + 1u : rl);
+    tp = skip ? p : tp;
+    const bool eot_sent = !sentence_end;  // the EOT fires a SentenceEnd unless one is pending
+    sentence_end = flush ? false : ((sent_eps || eot_now) ? true : sentence_end);
+    text_end = flush ? false : (eot_now ? true : text_end);
+    // retries keep the rune, everything else fetches a new one
+    t0 = backtrack ? eps_t : t0; aux0 = backtrack ? eps_aux : aux0;
+    p = backtrack ? eps_p : p; rl = backtrack ? eps_rl : rl;
+    a = backtrack ? epsilon : (retry_unknown ? unknown : a);
+    newchar = succ || hardfail;
+    const bool rewind = flush || (IS_MATRIX && eot_now);  // matrix.go:601 vs datok.go:1019-1030
+    eps_t = (backtrack || rewind) ? 0u : eps_t;
+    // rare: EOT calls, the reference's 1024-rune window limit (checked where the window was
+    // longest), end of this lane's chunk
+    if (eot_now || (rewind && (hi - bs > DTK_WINDOW || (MODE != MODE_DOC && p >= stop_pos)))) {
       if (eot_now) {
-        if (MODE != MODE_START) sink.template eot<IS_MATRIX>(p, !sentence_end, has_tok);
+        if (MODE != MODE_START) sink.template eot<IS_MATRIX>(p, eot_sent, has_tok);
         has_tok = false;  // TextEnd: pos = pos[:0] (token_writer.go:158)
       }
-      sentence_end = flush ? false : ((sent_eps || eot_now) ? true : sentence_end);
-      text_end = flush ? false : (eot_now ? true : text_end);
-      // retries keep the rune, everything else fetches a new one
-      t0 = backtrack ? eps_t : t0; aux0 = backtrack ? eps_aux : aux0;
-      p = backtrack ? eps_p : p; rl = backtrack ? eps_rl : rl;
-      a = backtrack ? epsilon : (retry_unknown ? unknown : a);
-      newchar = good || hardfail;
-      eot = false;  // consumed above, or cleared by a retry (matrix.go:555)
-      const bool rewind = flush || (IS_MATRIX && eot_now);  // matrix.go:601 vs datok.go:1019-1030
-      eps_t = (backtrack || rewind) ? 0u : eps_t;
-      if (rewind) {  // matrix.go:537-543 / 608-627
-        // the 1024-rune limit of the reference, checked where the window was longest
+      if (rewind) {
         if (hi - bs > DTK_WINDOW && count_runes(s, bs, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
-        tp = p; bs = p; rl = 0;
         if (MODE != MODE_DOC && p >= stop_pos) {
           fin.p = p; fin.t = t; fin.aux = aux;
           fin.flags = (sentence_end ? LANE_F_SENT : 0u) | (text_end ? LANE_F_TEXT : 0u) |
@@ -545,8 +545,10 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
           done = true;
         }
       }
-      if (my_steps > cap) { st |= ST_STEP_LIMIT; done = true; }
     }
+    tp = rewind ? p : tp;  // matrix.go:537-543 / 608-627
+    bs = rewind ? p : bs;
+    rl = rewind ? 0u : rl;
   } while (!done);
 
   if (!stopped && !(st & (ST_STEP_LIMIT | ST_BAD_MODEL))) {
