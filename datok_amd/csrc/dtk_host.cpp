@@ -506,10 +506,10 @@ extern "C" int dtk_batch_create(uint64_t max_bytes, uint32_t max_docs, dtk_batch
   B_TRY(hipMalloc((void **)&b->d_text_own, max_bytes + pad));
   B_TRY(hipMalloc((void **)&b->d_off_own, ((uint64_t)max_docs + 1) * 8));
   B_TRY(hipMalloc((void **)&b->d_sym, (max_bytes + pad) * 2));
-  B_TRY(hipMalloc((void **)&b->d_ev, 2 * (max_bytes + max_docs + pad)));
+  B_TRY(hipMalloc((void **)&b->d_ev, 2 * (max_bytes + 4ull * max_docs + pad)));
   b->acc_bytes = 64 + 3 * ((uint64_t)max_docs + 1) * 8 + 3 * (uint64_t)max_docs * 4 + 64;
   B_TRY(hipMalloc((void **)&b->d_acc, b->acc_bytes));
-  B_TRY(hipMalloc((void **)&b->d_tlen, (max_bytes + max_docs + pad) * 4));
+  B_TRY(hipMalloc((void **)&b->d_tlen, (max_bytes + 4ull * max_docs + pad) * 4));
   B_TRY(hipMalloc((void **)&b->d_redo, (uint64_t)max_docs * 4));
   B_TRY(hipMalloc((void **)&b->d_blk_doc, (max_bytes / DTK_SYM_BLOCK_BYTES + 3) * 4));
 
@@ -728,7 +728,7 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
     b->d_first_bad = (uint32_t *)q; q += nd * 4;
     b->d_fail_lane = (uint32_t *)q; q += nd * 4;
     HIP_TRY(hipMemsetAsync(b->d_acc, 0, (size_t)(q - b->d_acc), s));
-    const size_t ev_bytes = (b->total + nd + 255) & ~(size_t)255;
+    const size_t ev_bytes = (b->total + 4 * nd + 4 + 255) & ~(size_t)255;
     b->d_evA = b->d_ev;
     b->d_evB = b->d_ev + ev_bytes;
     HIP_TRY(hipMemsetAsync(b->d_ev, 0, 2 * ev_bytes, s));
@@ -890,8 +890,8 @@ extern "C" int dtk_batch_result_host(dtk_batch *b, dtk_result_view *o) {
   if ((rc = get(b->h_ttok, b->d_ttok, nx))) return rc;
   if ((rc = get(b->h_tsent, b->d_tsent, nx))) return rc;
   if ((rc = get(b->h_status, b->d_status, nd))) return rc;
-  if ((rc = get(b->h_events, b->d_evA, b->total + nd))) return rc;
-  if ((rc = get(b->h_events_b, b->d_evB, b->total + nd))) return rc;
+  if ((rc = get(b->h_events, b->d_evA, b->total + 4 * nd + 4))) return rc;
+  if ((rc = get(b->h_events_b, b->d_evB, b->total + 4 * nd + 4))) return rc;
   o->tok_off = b->h_tok_off.data(); o->sent_off = b->h_sent_off.data(); o->text_off = b->h_text_off.data();
   o->tok_rstart = b->h_rstart.data(); o->tok_rend = b->h_rend.data();
   o->tok_bstart = b->h_bstart.data(); o->tok_bend = b->h_bend.data();

@@ -36,6 +36,11 @@
 #define EV_SMASK (EV_S_EOT | EV_S_EPS | EV_S_EPS2 | EV_S_EOF)
 #define EV_EMASK (EV_E_EOT | EV_E_EOF)
 
+// Index of position 0 of document d (starting at input byte `off`) in the event /
+// token-length arrays: 4-byte aligned so that four positions load as one dword, and
+// one position more than the document has bytes.  Needs total + 4 * n_docs + 4 slots.
+#define DTK_EV_BASE(off, d) ((((uint64_t)(off)) + 4ull * (uint64_t)(d)) & ~3ull)
+
 // per-document status (mirrors DTK_ST_* of datok_gpu.h)
 #define ST_WINDOW_OVERFLOW 1u
 #define ST_EMPTY_TEXT 2u
@@ -120,7 +125,7 @@ struct DtkWalkArgs {
   const uint16_t *sym;      // symbol stream, one entry per input byte
   const uint64_t *doc_off;  // n_docs + 1
   uint32_t n_docs;
-  uint8_t *evA, *evB;       // closing / opening event bytes, zero-filled; index doc_off[d] + d + p
+  uint8_t *evA, *evB;       // closing / opening event bytes, zero-filled; index DTK_EV_BASE + p
   uint32_t *tlen;           // token byte length | rune length << 16, at the token's end position
   uint32_t *status;         // per document, OR-ed
   uint64_t *tok_cnt, *sent_cnt, *text_cnt;  // per document: what the writer would have collected

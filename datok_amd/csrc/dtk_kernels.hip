@@ -588,7 +588,8 @@ __global__ __launch_bounds__(WAVE) void k_walk_doc(TRANS tr, DtkWalkArgs A, uint
     const uint64_t off = A.doc_off[d];
     const uint32_t len = (uint32_t)(A.doc_off[d + 1] - off);
     EventSink sink;
-    sink.init(A.evA + off + d, A.evB + off + d, A.tlen + off + d, 0u, 0xFFFFFFFFu);
+    const uint64_t evb = DTK_EV_BASE(off, d);
+    sink.init(A.evA + evb, A.evB + evb, A.tlen + evb, 0u, 0xFFFFFFFFu);
     DtkLaneState init{0u, tr.start_state(), tr.start_aux(), 0u}, fin;
     uint32_t st;
     walk_lane<TRANS, IS_MATRIX, MODE_DOC>(tr, A.sym, off, len, init, 0u, sink, epsilon, unknown,
@@ -754,7 +755,8 @@ __global__ __launch_bounds__(WAVE) void k_spec_walk(TRANS tr, DtkWalkArgs A, Dtk
         const uint32_t len = (uint32_t)(A.doc_off[d + 1] - off);
         const DtkLaneState init = S.lane_start[L];
         EventSink sink;
-        sink.init(A.evA + off + d, A.evB + off + d, A.tlen + off + d, init.p, pl.wend);
+        const uint64_t evb = DTK_EV_BASE(off, d);
+        sink.init(A.evA + evb, A.evB + evb, A.tlen + evb, init.p, pl.wend);
         uint32_t st = 0;
         walk_lane<TRANS, IS_MATRIX, MODE_CHUNK>(tr, A.sym, off, len, init, pl.stop, sink, epsilon, unknown,
                                                 identity, step_cap(A.step_factor, len), fin, st, steps);
@@ -870,7 +872,7 @@ __global__ __launch_bounds__(WAVE) void k_spec_clear(DtkWalkArgs A, DtkSpecArgs 
   const uint64_t off = A.doc_off[d];
   const uint32_t len = (uint32_t)(A.doc_off[d + 1] - off);
   const uint32_t from = S.lane_start[S.redo_from[d]].p;
-  uint8_t *a = A.evA + off + d, *b = A.evB + off + d;
+  uint8_t *a = A.evA + DTK_EV_BASE(off, d), *b = A.evB + DTK_EV_BASE(off, d);
   for (uint32_t q = from + threadIdx.x; q <= len; q += WAVE) {
     if (q > from) a[q] = 0;  // the closing byte at `from` belongs to the previous lane
     b[q] = 0;
@@ -897,15 +899,26 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total) 
   return x - v;
 }
 
-template <bool WRITE>
+#define CQ_CAP 512u  // ring capacity in events (power of two; one light tile adds at most 256)
+
+// One wave per document.  Light phase: 256 cursor positions per iteration (4 per
+// lane) -- OR the two event bytes, count rune starts, and append the positions
+// that carry events (about 0.3 per input byte) with their rune index to a ring in
+// LDS, using one packed wave scan.  Heavy phase: whenever 64 events are queued
+// (or at the end), lane i takes the i-th event and everything NewTokenWriter
+// tracks (token_writer.go:38-42: posC, pos, sentB, sent) is recovered with ballots,
+// popcounts of the lanes below and a handful of shuffles; wave-uniform carries link
+// the rounds.  Order of the calls at one position = bit order of the event byte.
 __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
+  __shared__ uint32_t qpos[CQ_CAP], qfl[CQ_CAP], qrn[CQ_CAP];
   const uint32_t d = blockIdx.x;
   if (d >= A.n_docs) return;
   const uint64_t off = A.doc_off[d];
   const uint32_t len = (uint32_t)(A.doc_off[d + 1] - off);
-  const uint8_t *__restrict__ evA = A.evA + off + d;
-  const uint8_t *__restrict__ evB = A.evB + off + d;
-  const uint32_t *__restrict__ tlen = A.tlen + off + d;
+  const uint64_t evb = DTK_EV_BASE(off, d);
+  const uint8_t *__restrict__ evA = A.evA + evb;
+  const uint8_t *__restrict__ evB = A.evB + evb;
+  const uint32_t *__restrict__ tlen = A.tlen + evb;
   const uint16_t *__restrict__ sym = A.sym + off;
   const uint8_t *__restrict__ txt = A.text + off;
   const bool nl_rule = (A.flags & 16u) != 0;  // NEWLINE_AFTER_EOT
@@ -913,20 +926,17 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
   const uint32_t lane = lane_id();
   const unsigned long long lt = lanemask_lt();
 
-  uint64_t tok_base = 0, sent_base = 0, text_base = 0, tok_lim = 0, sent_lim = 0, text_lim = 0;
-  if (WRITE) {
-    // rows were sized by pass 1 + scan; skip everything if the output arrays are too
-    // small (the host grows them and re-launches this pass)
-    if (A.totals[0] > A.tok_cap || A.totals[1] > A.sent_cap || A.totals[2] > A.text_cap) return;
-    tok_base = A.tok_off[d]; sent_base = A.sent_off[d]; text_base = A.text_off[d];
-    tok_lim = A.tok_off[d + 1]; sent_lim = A.sent_off[d + 1]; text_lim = A.text_off[d + 1];
-  }
+  // rows were sized by the walk's counts + scan; skip everything if the output arrays
+  // are too small (the host grows them and re-launches this pass)
+  if (A.totals[0] > A.tok_cap || A.totals[1] > A.sent_cap || A.totals[2] > A.text_cap) return;
+  const uint64_t tok_base = A.tok_off[d], sent_base = A.sent_off[d], text_base = A.text_off[d];
+  const uint64_t tok_lim = A.tok_off[d + 1], sent_lim = A.sent_off[d + 1], text_lim = A.text_off[d + 1];
 
   // wave-uniform carries
-  uint32_t cR = 0;           // runes started before the tile
-  uint32_t cTE = 0;          // token ends before the tile
-  uint32_t cNE = 0, cNSev = 0;  // TextEnd / SentenceEnd calls before the tile
-  uint32_t cNSent = 0;       // sentence ints pushed before the tile
+  uint32_t cR = 0;           // runes started before the light tile
+  uint32_t cTE = 0;          // token ends before the heavy round
+  uint32_t cNE = 0, cNSev = 0;  // TextEnd / SentenceEnd calls before the round
+  uint32_t cNSent = 0;       // sentence ints pushed before the round
   uint32_t cSEatEnd = 0, cEatEnd = 0;  // calls seen when the last token ended
   uint32_t cLastEndR = 0, cLastEndByte = 0;
   int32_t cLastRend = 0;
@@ -934,31 +944,65 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
   uint32_t cLastER = 0, cLastEByte = 0, cTokAtLastE = 0;
   bool cHaveE = false;
   uint32_t status = 0;
+  uint32_t qhead = 0, qn = 0;  // ring: first entry, entries queued
 
-  for (uint32_t base = 0; base <= len; base += WAVE) {
-    const uint32_t P = base + lane;
-    uint32_t f = 0, rs = 0, tb = 0;
-    if (P <= len) f = (uint32_t)evA[P] | (uint32_t)evB[P];
-    if (P < len) {
-      rs = sym[P] >> 15;
-      tb = txt[P];
+  const uint32_t n_pos = len + 1u;  // cursor positions 0..len
+  for (uint32_t base = 0; base < n_pos; base += 4u * WAVE) {
+    // ---- light phase
+    const uint32_t P0 = base + lane * 4u;
+    uint32_t fw = 0, rsn = 0;  // 4 event bytes (one per position), rune-start nibble
+    if (P0 < n_pos) {
+      // DTK_EV_BASE is 4-byte aligned and the arrays are padded: whole dwords are readable,
+      // bytes behind position `len` are zero (cleared, never written)
+      fw = *reinterpret_cast<const uint32_t *>(evA + P0) | *reinterpret_cast<const uint32_t *>(evB + P0);
+      const uint32_t left = n_pos - P0;  // positions of mine that exist
+      if (left < 4u) fw &= (1u << (8u * left)) - 1u;
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (P0 + j < len) rsn |= (uint32_t)(sym[P0 + j] >> 15) << j;
     }
+    const uint32_t evn = ((fw & 0xFFu) ? 1u : 0u) | ((fw & 0xFF00u) ? 2u : 0u) | ((fw & 0xFF0000u) ? 4u : 0u) |
+                         ((fw & 0xFF000000u) ? 8u : 0u);
+    uint32_t tot;
+    const uint32_t ex = wave_excl_scan((uint32_t)__popc(evn) | ((uint32_t)__popc(rsn) << 16), tot);
+    uint32_t slot = qhead + qn + (ex & 0xFFFFu);
+    const uint32_t Rl = cR + (ex >> 16);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (evn & (1u << j)) {
+        const uint32_t at = slot & (CQ_CAP - 1u);
+        qpos[at] = P0 + j;
+        qfl[at] = (fw >> (8 * j)) & 0xFFu;
+        qrn[at] = Rl + (uint32_t)__popc(rsn & ((1u << j) - 1u));
+        slot++;
+      }
+    }
+    qn += tot & 0xFFFFu;
+    cR += tot >> 16;
+    __syncthreads();
+    const bool last_tile = base + 4u * WAVE >= n_pos;
+
+    // ---- heavy phase
+    while (qn >= WAVE || (last_tile && qn > 0)) {
+    const uint32_t take = qn < WAVE ? qn : WAVE;
+    uint32_t P = 0, f = 0, R = 0, tb = 0;
+    if (lane < take) {
+      const uint32_t at = (qhead + lane) & (CQ_CAP - 1u);
+      P = qpos[at]; f = qfl[at]; R = qrn[at];
+      if ((f & (EV_TOK_END | EV_E_EOT)) && P < len) tb = txt[P];  // byte behind a token / an EOT
+    }
+    qhead += take;
+    qn -= take;
     const unsigned long long mEND = __ballot(f & EV_TOK_END);
-    const unsigned long long mRS = __ballot(rs);
     const unsigned long long mEEOT = __ballot(f & EV_E_EOT);
     const unsigned long long mEEOF = __ballot(f & EV_E_EOF);
     const unsigned long long mS1 = __ballot(f & EV_S_EOT);
     const unsigned long long mS2 = __ballot(f & EV_S_EPS);
     const unsigned long long mS3 = __ballot(f & EV_S_EPS2);
     const unsigned long long mS4 = __ballot(f & EV_S_EOF);
-    if ((mEND | mEEOT | mEEOF | mS1 | mS2 | mS3 | mS4) == 0ull) {
-      cR += popc(mRS);
-      continue;
-    }
 
     // Order of the calls at one position (bit order): S_EOT, E_EOT, TOK_END,
     // S_EPS, S_EPS2, S_EOF, E_EOF.
-    const uint32_t R = cR + popc(mRS & lt);
     const uint32_t te = cTE + popc(mEND & lt);   // tokens ended at lower positions
     const bool isEnd = (f & EV_TOK_END) != 0;
     const bool hasEEOT = (f & EV_E_EOT) != 0;
@@ -1039,7 +1083,7 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
     uint32_t cTotal;
     const uint32_t excl = wave_excl_scan(c, cTotal);
 
-    if (WRITE) {
+    {
       if (isEnd && tok_base + k < tok_lim) {
         A.tok_bstart[tok_base + k] = P - (tl & 0xFFFFu);
         A.tok_bend[tok_base + k] = P;
@@ -1088,28 +1132,23 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
       cTokAtLastE = __shfl(te, jl);
       cHaveE = true;
     }
-    cR += popc(mRS);
     cTE += popc(mEND);
     cNE += popc(mEEOT) + popc(mEEOF);
     cNSev += popc(mS1) + popc(mS2) + popc(mS3) + popc(mS4);
     cNSent += cTotal;
+    }  // heavy rounds
+    __syncthreads();
   }
 
-  // Pass 1 (WRITE == false) is only kept as a cross-check tool; the pipeline sizes the
-  // rows from the walk's own counts.  Either way the counts must agree with this pass.
+  // the walk's counts sized the rows: they must agree with what was written here
   uint32_t sred = status;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) sred |= __shfl_down(sred, o);
   sred = __shfl(sred, 0);
   if (lane == 0) {
-    if (!WRITE) {
-      A.tok_off[d] = cTE;
-      A.sent_off[d] = cNSent;
-      A.text_off[d] = cNE;
-    } else if (tok_base + cTE != tok_lim || sent_base + cNSent != sent_lim || text_base + cNE != text_lim) {
+    if (tok_base + cTE != tok_lim || sent_base + cNSent != sent_lim || text_base + cNE != text_lim)
       sred |= ST_INTERNAL;
-    }
-    if (WRITE) sred &= ST_INTERNAL;  // everything else was reported by the walk already
+    sred &= ST_INTERNAL;  // everything else was reported by the walk already
     if (sred) atomicOr(&A.status[d], sred);
   }
 }
@@ -1247,10 +1286,8 @@ extern "C" int dtk_launch_spec(const DtkTableDev *tab, const DtkWalkArgs *args, 
 extern "C" int dtk_launch_compact(const DtkCompactArgs *args, int pass, void *stream) {
   if (args->n_docs == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  if (pass == 1)
-    hipLaunchKernelGGL(k_compact<false>, dim3(args->n_docs), dim3(WAVE), 0, s, *args);
-  else
-    hipLaunchKernelGGL(k_compact<true>, dim3(args->n_docs), dim3(WAVE), 0, s, *args);
+  (void)pass;
+  hipLaunchKernelGGL(k_compact, dim3(args->n_docs), dim3(WAVE), 0, s, *args);
   return (int)hipGetLastError();
 }
 

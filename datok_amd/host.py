@@ -226,6 +226,11 @@ def load_tokenizer_file(path):
 
 
 # ----------------------------------------------------------------------- Batch
+def event_base(doc_off_d, d):
+    """DTK_EVENT_BASE: index of position 0 of document d in the event arrays."""
+    return (int(doc_off_d) + 4 * int(d)) & ~3
+
+
 class BatchResult:
     """Host copy of dtk_result_view (CSR over documents)."""
     __slots__ = ("tok_off", "sent_off", "text_off", "tok_rstart", "tok_rend", "tok_bstart",
@@ -344,6 +349,7 @@ class Batch:
         r.text_tok_end = arr(v.text_tok_end, t["n_texts"], np.uint32)
         r.text_sent_end = arr(v.text_sent_end, t["n_texts"], np.uint32)
         r.status = arr(v.status, nd, np.uint32)
-        r.events = arr(v.events, self.total + nd, np.uint8) | arr(v.events_open, self.total + nd, np.uint8)
+        n_ev = self.total + 4 * nd + 4
+        r.events = arr(v.events, n_ev, np.uint8) | arr(v.events_open, n_ev, np.uint8)
         r.doc_off = self._doc_off
         return r

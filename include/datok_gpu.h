@@ -170,7 +170,7 @@ typedef struct {
   const uint32_t *text_tok_end, *text_sent_end;
   const uint32_t *status;
   /* raw walk output, for replay into TokenWriter closures: one byte per byte
-   * position of every document plus one (index doc_off[d] + d + p).  The calls
+   * position p = 0..len of every document, at index DTK_EVENT_BASE(doc_off[d], d) + p.  The calls
    * fired by a window rewind (S_EOT, E_EOT, TOK_END) are in `events`, all
    * others in `events_open`; OR the two bytes.  The k-th TOK_END of a document
    * belongs to its k-th token (tok_bstart/tok_bend). */
@@ -181,6 +181,9 @@ int dtk_batch_result_device(dtk_batch *b, dtk_result_view *out);
 /* Copies the arrays to host memory owned by the batch (valid until the next
  * run / free) and returns host pointers in the same struct. */
 int dtk_batch_result_host(dtk_batch *b, dtk_result_view *out);
+
+/* index of position 0 of document d in dtk_result_view.events / events_open */
+#define DTK_EVENT_BASE(doc_off_d, d) ((((uint64_t)(doc_off_d)) + 4ull * (uint64_t)(d)) & ~3ull)
 
 /* event byte layout of dtk_result_view.events (chronological order = bit order) */
 enum {
