@@ -29,42 +29,31 @@ __device__ __forceinline__ unsigned long long lanemask_lt() { return (1ull << la
 __device__ __forceinline__ int highest(unsigned long long m) { return 63 - __clzll((long long)m); }
 __device__ __forceinline__ uint32_t popc(unsigned long long m) { return (uint32_t)__popcll(m); }
 
-// Go unicode/utf8.DecodeRune on up to 4 bytes (b0..b3), `avail` of which exist
-// in the document (the decoder behind bufio.ReadRune, matrix.go:392).
-__device__ __forceinline__ uint32_t go_decode(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3,
-                                              uint32_t avail, uint32_t &rune) {
-  rune = 0xFFFDu;
-  if (b0 < 0x80u) { rune = b0; return 1; }
-  if (b0 < 0xC2u || b0 > 0xF4u) return 1;
-  if (b0 < 0xE0u) {
-    if (avail < 2 || (b1 & 0xC0u) != 0x80u) return 1;
-    rune = ((b0 & 0x1Fu) << 6) | (b1 & 0x3Fu);
-    return 2;
+// exclusive prefix sum over the 64 lanes; total = sum of all lanes
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total) {
+  uint32_t x = v;
+#pragma unroll
+  for (int o = 1; o < WAVE; o <<= 1) {
+    uint32_t y = __shfl_up(x, o);
+    if ((int)lane_id() >= o) x += y;
   }
-  if (b0 < 0xF0u) {
-    uint32_t lo = b0 == 0xE0u ? 0xA0u : 0x80u, hi = b0 == 0xEDu ? 0x9Fu : 0xBFu;
-    if (avail < 3 || b1 < lo || b1 > hi || (b2 & 0xC0u) != 0x80u) return 1;
-    rune = ((b0 & 0x0Fu) << 12) | ((b1 & 0x3Fu) << 6) | (b2 & 0x3Fu);
-    return 3;
-  }
-  uint32_t lo = b0 == 0xF0u ? 0x90u : 0x80u, hi = b0 == 0xF4u ? 0x8Fu : 0xBFu;
-  if (avail < 4 || b1 < lo || b1 > hi || (b2 & 0xC0u) != 0x80u || (b3 & 0xC0u) != 0x80u) return 1;
-  rune = ((b0 & 0x07u) << 18) | ((b1 & 0x3Fu) << 12) | ((b2 & 0x3Fu) << 6) | (b3 & 0x3Fu);
-  return 4;
+  total = __shfl(x, WAVE - 1);
+  return x - v;
 }
 
 // ---------------------------------------------------------------- symbolise
 //
-// One lane per 4 input bytes, a 256-thread block per 4 KiB.  Each lane decodes
-// its four positions "as if a rune started there" with Go's DecodeRune rules
-// (straight-line selects, no divergence), looks the rune up (runes < 256 through a
-// 256-entry table in LDS, the few others by binary search) and decides whether the
-// position really starts a rune from the widths of the three positions before it.
-// The neighbouring dwords come from the adjacent lanes by shuffle.  Documents
-// never share a rune: look-back and look-ahead stop at the document boundary
-// (reader EOF, matrix.go:394-399).
-
-#define SYM_BLOCK_BYTES DTK_SYM_BLOCK_BYTES
+// One wave per 4 KiB of input, 256 bytes (4 per lane) per iteration.
+//   light: every byte < 0x80 is a complete rune: its entry comes from a 256-entry
+//          table in LDS.  Positions holding a byte >= 0x80 (a few percent of
+//          European text) are appended to a small queue in LDS.
+//   heavy: lane i takes the i-th queued position and decodes it with Go's
+//          DecodeRune rules (matrix.go:392), decides whether that byte really
+//          starts a rune (look-back of up to 3 bytes) and looks the rune up in
+//          the sigma map (also in LDS).  Documents never share a rune: look-back
+//          and look-ahead stop at the document boundary (reader EOF,
+//          matrix.go:394-399).
+// The 256 entries of the iteration are assembled in LDS and leave as 8-byte stores.
 
 // width Go's DecodeRune reports at a position (b0 first byte, `avail` bytes left in the
 // document).  Integer predicates on purpose: bool && chains become branches.
@@ -90,161 +79,141 @@ __device__ __forceinline__ uint32_t doc_of(const uint64_t *__restrict__ doc_off,
   return lo;
 }
 
+#define SYM_BLOCK_BYTES DTK_SYM_BLOCK_BYTES
+#define SYM_TILE 256u
+
 template <bool ALIGNED4>
-__global__ __launch_bounds__(256) void k_symbolize(const uint8_t *__restrict__ text,
-                                                   const uint64_t *__restrict__ doc_off,
-                                                   uint32_t n_docs, uint64_t total, DtkSigmaDev sig,
-                                                   uint16_t *__restrict__ sym,
-                                                   const uint32_t *__restrict__ blk_doc) {
-  __shared__ uint16_t lut[256];
-  __shared__ uint32_t s_pack[4];     // decode summary of each wave's last lane, for the next wave
-  __shared__ uint32_t s_runes[256];  // sigma map (runes >= 256 are rare but a global-memory binary
-  __shared__ uint16_t s_syms[256];   // search would stall the whole wave for one lane)
-  const uint32_t tid = threadIdx.x, wv = tid >> 6, ln = tid & 63u;
+__global__ __launch_bounds__(WAVE) void k_symbolize(const uint8_t *__restrict__ text,
+                                                    const uint64_t *__restrict__ doc_off,
+                                                    uint32_t n_docs, uint64_t total, DtkSigmaDev sig,
+                                                    uint16_t *__restrict__ sym,
+                                                    const uint32_t *__restrict__ blk_doc) {
+  __shared__ uint16_t lut[256];       // symbol | class | START for runes < 128 (index = byte)
+  __shared__ uint16_t lat[256];       // symbol | class for runes < 256 (heavy path, Latin-1)
+  __shared__ uint32_t s_runes[256];   // sigma map (runes >= 256)
+  __shared__ uint16_t s_syms[256];
+  __shared__ uint16_t s_out[SYM_TILE];
+  __shared__ uint16_t s_q[SYM_TILE];  // queued positions (offset inside the tile)
+  const uint32_t lane = threadIdx.x;
   const bool sig_lds = sig.n_runes <= 256u;
-  if (sig_lds && tid < sig.n_runes) { s_runes[tid] = sig.runes[tid]; s_syms[tid] = sig.syms[tid]; }
-  // symbol | class for every rune < 256 (matrix.go:421-426)
-  lut[tid] = (uint16_t)((sig.ascii[tid] & DTK_SYM_MASK) | (tid == DTK_EOT ? (1u << DTK_SYM_CLS_SHIFT) : 0u));
-  const uint64_t block_start = (uint64_t)blockIdx.x * SYM_BLOCK_BYTES;
-  const uint64_t block_last = min(block_start + SYM_BLOCK_BYTES, total) - 1;
+  for (uint32_t i = lane; i < 256u; i += WAVE) {
+    // matrix.go:421-426: runes < 256 go through sigmaASCII; rune 4 is EOT
+    const uint32_t e = (sig.ascii[i] & DTK_SYM_MASK) | (i == DTK_EOT ? (1u << DTK_SYM_CLS_SHIFT) : 0u);
+    lat[i] = (uint16_t)e;
+    lut[i] = (uint16_t)(e | DTK_SYM_START);
+    if (sig_lds && i < sig.n_runes) { s_runes[i] = sig.runes[i]; s_syms[i] = sig.syms[i]; }
+  }
   __syncthreads();
+  const uint64_t block_start = (uint64_t)blockIdx.x * SYM_BLOCK_BYTES;
   // documents that can own bytes of this block: host-computed (document of each block's
   // first byte), so no lane walks the offset table from scratch
   const uint32_t d_lo = blk_doc[blockIdx.x];
   const uint32_t d_hi = min(blk_doc[blockIdx.x + 1], n_docs - 1);
-  (void)block_last;
-
-  auto load4 = [&](uint64_t g) -> uint32_t {  // bytes g..g+3, zero behind the end
-    if (ALIGNED4) {
-      // the text buffer is padded: a dword that straddles the end is readable, mask it
-      const uint32_t x = *reinterpret_cast<const uint32_t *>(text + g);
-      const uint64_t left = total - g;
-      return left >= 4 ? x : (x & ((1u << (8 * (uint32_t)left)) - 1u));
-    }
-    uint32_t x = 0;
-    for (int k = 0; k < 4; k++)
-      if (g + k < total) x |= (uint32_t)text[g + k] << (8 * k);
-    return x;
-  };
 
 #pragma unroll 1
-  for (uint32_t it = 0; it < SYM_BLOCK_BYTES / 1024u; it++) {
-    const uint64_t g0 = block_start + it * 1024u + tid * 4u;
-    const bool live = g0 < total;
-    const uint32_t w = live ? load4(g0) : 0u;
-    uint32_t wn = __shfl_down(w, 1);  // the next dword sits in the next lane of the wave
-    if (ln == 63u) wn = (live && g0 + 4 < total) ? load4(g0 + 4) : 0u;
-
-    uint32_t b[7];  // b[0..3] own bytes, b[4..6] look-ahead
-    b[0] = w & 0xFFu; b[1] = (w >> 8) & 0xFFu; b[2] = (w >> 16) & 0xFFu; b[3] = w >> 24;
-    b[4] = wn & 0xFFu; b[5] = (wn >> 8) & 0xFFu; b[6] = (wn >> 16) & 0xFFu;
-
-    // per position: bytes left in its document / bytes behind it in its document,
-    // saturated at 8.  Far from a document boundary (the usual case) both are 8.
-    uint32_t left[4] = {8u, 8u, 8u, 8u}, back[4] = {8u, 8u, 8u, 8u};
-    if (live) {
-      uint32_t d = d_lo == d_hi ? d_lo : doc_of(doc_off, d_lo, d_hi + 1, g0);
-      uint64_t dstart = doc_off[d], dend = doc_off[d + 1];
-      if (dend - g0 < 12 || g0 - dstart < 4) {  // a boundary within reach: exact values
-        for (int j = 0; j < 4; j++) {
-          const uint64_t g = g0 + j;
-          if (g < total) {
-            while (g >= dend) { d++; dstart = dend; dend = doc_off[d + 1]; }  // next document(s)
-            const uint64_t l = dend - g, bk = g - dstart;
-            left[j] = l > 8 ? 8u : (uint32_t)l;
-            back[j] = bk > 8 ? 8u : (uint32_t)bk;
-          } else {
-            left[j] = 0; back[j] = 0;
-          }
-        }
-      }
-    }
-    uint32_t pk = 0, width[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      width[j] = go_width(b[j], b[j + 1], b[j + 2], b[j + 3], left[j]);
-      pk |= (width[j] - 1u) << (2 * j);
-      pk |= ((b[j] & 0xC0u) != 0x80u ? 1u : 0u) << (8 + j);
-    }
-    // the same summary of the 4 positions before mine
-    uint32_t pp = __shfl_up(pk, 1);
-    if (ln == 63u) s_pack[wv] = pk;
-    __syncthreads();
-    if (ln == 0) {
-      if (wv > 0) {
-        pp = s_pack[wv - 1];
-      } else if (live && g0 >= 4) {  // first lane of the block: decode the previous dword myself
-        const uint32_t wp = load4(g0 - 4);
-        const uint32_t bb[7] = {wp & 0xFFu, (wp >> 8) & 0xFFu, (wp >> 16) & 0xFFu, wp >> 24, b[0], b[1], b[2]};
-        // those positions are only consulted when they lie in my document (k <= back),
-        // where "bytes left" is mine + 4
-        const uint32_t l0 = left[0] + 4u > 8u ? 8u : left[0] + 4u;
-        pp = 0;
-        for (int j = 0; j < 4; j++) {
-          const uint32_t wd = go_width(bb[j], bb[j + 1], bb[j + 2], bb[j + 3], l0 > (uint32_t)j ? l0 - j : 0u);
-          pp |= (wd - 1u) << (2 * j);
-          pp |= ((bb[j] & 0xC0u) != 0x80u ? 1u : 0u) << (8 + j);
-        }
+  for (uint32_t it = 0; it < SYM_BLOCK_BYTES / SYM_TILE; it++) {
+    const uint64_t tile0 = block_start + (uint64_t)it * SYM_TILE;
+    if (tile0 >= total) break;
+    const uint64_t g0 = tile0 + lane * 4u;
+    // ---- light: 4 bytes per lane
+    uint32_t w = 0;
+    if (g0 < total) {
+      if (ALIGNED4) {
+        // the text buffer is padded (or a multiple of 4): a dword that straddles the end is readable
+        w = *reinterpret_cast<const uint32_t *>(text + g0);
       } else {
-        pp = 0;
+        for (int k = 0; k < 4; k++)
+          if (g0 + k < total) w |= (uint32_t)text[g0 + k] << (8 * k);
+      }
+    }
+    const uint32_t left = g0 < total ? (total - g0 >= 4 ? 4u : (uint32_t)(total - g0)) : 0u;
+    const uint32_t hib = (w & 0x80808080u) & (left >= 4 ? 0xFFFFFFFFu : ((1u << (8u * left)) - 1u));
+    const uint32_t rare = ((hib >> 7) & 1u) | ((hib >> 14) & 2u) | ((hib >> 21) & 4u) | ((hib >> 28) & 8u);
+    s_out[lane * 4u + 0u] = lut[w & 0x7Fu];
+    s_out[lane * 4u + 1u] = lut[(w >> 8) & 0x7Fu];
+    s_out[lane * 4u + 2u] = lut[(w >> 16) & 0x7Fu];
+    s_out[lane * 4u + 3u] = lut[(w >> 24) & 0x7Fu];
+    uint32_t nq;
+    uint32_t slot = wave_excl_scan((uint32_t)__popc(rare), nq);
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (rare & (1u << j)) s_q[slot++] = (uint16_t)(lane * 4u + j);
+    __syncthreads();
+
+    // ---- heavy: one queued position per lane
+    for (uint32_t q0 = 0; q0 < nq; q0 += WAVE) {
+      if (q0 + lane < nq) {
+        const uint32_t pos = s_q[q0 + lane];
+        const uint64_t g = tile0 + pos;
+        // my document
+        uint32_t d = d_lo == d_hi ? d_lo : doc_of(doc_off, d_lo, d_hi + 1, g);
+        const uint64_t dstart = doc_off[d], dend = doc_off[d + 1];
+        const uint64_t l64 = dend - g, b64 = g - dstart;
+        const uint32_t avail = l64 > 8 ? 8u : (uint32_t)l64, back = b64 > 3 ? 3u : (uint32_t)b64;
+        // bytes g-3 .. g+3 (inside the document; the tile was just read, these hit in cache)
+        uint32_t bb[7];
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+          const int o = k - 3;
+          const bool in = o < 0 ? (uint32_t)(-o) <= back : (uint32_t)o < avail;
+          bb[k] = in ? (uint32_t)text[g + o] : 0u;
+        }
+        const uint32_t b0 = bb[3], b1 = bb[4], b2 = bb[5], b3 = bb[6];
+        const uint32_t wd = go_width(b0, b1, b2, b3, avail);
+        // rune value for the decoded width (U+FFFD for an invalid byte; b0 >= 0x80 here)
+        const uint32_t r2 = ((b0 & 0x1Fu) << 6) | (b1 & 0x3Fu);
+        const uint32_t r3 = ((b0 & 0x0Fu) << 12) | ((b1 & 0x3Fu) << 6) | (b2 & 0x3Fu);
+        const uint32_t r4 = ((b0 & 0x07u) << 18) | ((b1 & 0x3Fu) << 12) | ((b2 & 0x3Fu) << 6) | (b3 & 0x3Fu);
+        const uint32_t rune = wd == 1 ? 0xFFFDu : (wd == 2 ? r2 : (wd == 3 ? r3 : r4));
+        // does this byte start a rune?  a non-continuation byte always does; a
+        // continuation byte does unless the nearest non-continuation byte within the
+        // previous 3 (same document) begins a valid sequence that reaches it.
+        uint32_t start = 1, open = (b0 & 0xC0u) == 0x80u;  // open: still looking
+#pragma unroll
+        for (int k = 1; k <= 3; k++) {
+          const uint32_t l0 = bb[3 - k];
+          const uint32_t noncont = (l0 & 0xC0u) != 0x80u;
+          const uint32_t inside = (uint32_t)k <= back;
+          const uint32_t w2 = go_width(l0, bb[4 - k], bb[5 - k], bb[6 - k], avail + (uint32_t)k);
+          const uint32_t cand = open & inside & noncont;
+          start = cand ? (uint32_t)(w2 <= (uint32_t)k) : start;
+          open = open & inside & (noncont ^ 1u);
+        }
+        uint32_t a_cls;
+        if (rune < 256u) {
+          a_cls = lat[rune];
+        } else {  // matrix.go:427-435: a, ok = sigma[char]; !ok -> identity
+          int l = 0, h = (int)sig.n_runes - 1;
+          a_cls = (sig.identity & DTK_SYM_MASK) | (3u << DTK_SYM_CLS_SHIFT);
+          while (l <= h) {
+            const int m = (l + h) >> 1;
+            const uint32_t r = sig_lds ? s_runes[m] : sig.runes[m];
+            if (r == rune) {
+              a_cls = ((sig_lds ? (uint32_t)s_syms[m] : (uint32_t)sig.syms[m]) & DTK_SYM_MASK) |
+                      (2u << DTK_SYM_CLS_SHIFT);
+              break;
+            }
+            if (r < rune) l = m + 1; else h = m - 1;
+          }
+        }
+        s_out[pos] = (uint16_t)(a_cls | ((wd - 1) << DTK_SYM_W_SHIFT) | (start ? DTK_SYM_START : 0u));
       }
     }
     __syncthreads();
-    if (!live) continue;
 
-    const uint32_t both = pp | (pk << 16);  // positions -4..-1 in the low half, 0..3 in the high half
-    uint32_t out[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const uint32_t b0 = b[j], b1 = b[j + 1], b2 = b[j + 2], b3 = b[j + 3];
-      const uint32_t wd = width[j];
-      // rune value for the decoded width (U+FFFD for an invalid byte)
-      const uint32_t r2 = ((b0 & 0x1Fu) << 6) | (b1 & 0x3Fu);
-      const uint32_t r3 = ((b0 & 0x0Fu) << 12) | ((b1 & 0x3Fu) << 6) | (b2 & 0x3Fu);
-      const uint32_t r4 = ((b0 & 0x07u) << 18) | ((b1 & 0x3Fu) << 12) | ((b2 & 0x3Fu) << 6) | (b3 & 0x3Fu);
-      const uint32_t r1 = b0 < 0x80u ? b0 : 0xFFFDu;
-      const uint32_t rune = wd == 1 ? r1 : (wd == 2 ? r2 : (wd == 3 ? r3 : r4));
-      // does this byte start a rune?  a non-continuation byte always does; a
-      // continuation byte does unless the nearest non-continuation byte within the
-      // previous 3 (same document) begins a valid sequence that reaches it.
-      uint32_t start = 1, open = (b0 & 0xC0u) == 0x80u;  // open: still looking
-#pragma unroll
-      for (int k = 1; k <= 3; k++) {
-        const int q = j - k;  // position index: >= 0 mine, < 0 previous lane's
-        const uint32_t sh_w = q >= 0 ? 16 + 2 * q : 2 * (q + 4);
-        const uint32_t sh_n = q >= 0 ? 24 + q : 8 + (q + 4);
-        const uint32_t w2 = ((both >> sh_w) & 3u) + 1u;
-        const uint32_t noncont = (both >> sh_n) & 1u;
-        const uint32_t inside = (uint32_t)k <= back[j];
-        const uint32_t cand = open & inside & noncont;
-        start = cand ? (uint32_t)(w2 <= (uint32_t)k) : start;
-        open = open & inside & (noncont ^ 1u);
+    // ---- store the tile
+    if (g0 < total) {
+      const uint32_t o01 = *reinterpret_cast<const uint32_t *>(&s_out[lane * 4u]);
+      const uint32_t o23 = *reinterpret_cast<const uint32_t *>(&s_out[lane * 4u + 2u]);
+      if (g0 + 4 <= total) {
+        *reinterpret_cast<uint2 *>(sym + g0) = make_uint2(o01, o23);
+      } else {
+        const uint32_t o[4] = {o01 & 0xFFFFu, o01 >> 16, o23 & 0xFFFFu, o23 >> 16};
+        for (int j = 0; j < 4; j++)
+          if (g0 + j < total) sym[g0 + j] = (uint16_t)o[j];
       }
-      uint32_t a_cls;
-      if (rune < 256u) {
-        a_cls = lut[rune];
-      } else {  // matrix.go:427-435: a, ok = sigma[char]; !ok -> identity
-        int l = 0, h = (int)sig.n_runes - 1;
-        a_cls = (sig.identity & DTK_SYM_MASK) | (3u << DTK_SYM_CLS_SHIFT);
-        while (l <= h) {
-          const int m = (l + h) >> 1;
-          const uint32_t r = sig_lds ? s_runes[m] : sig.runes[m];
-          if (r == rune) {
-            a_cls = ((sig_lds ? (uint32_t)s_syms[m] : (uint32_t)sig.syms[m]) & DTK_SYM_MASK) |
-                    (2u << DTK_SYM_CLS_SHIFT);
-            break;
-          }
-          if (r < rune) l = m + 1; else h = m - 1;
-        }
-      }
-      out[j] = a_cls | ((wd - 1) << DTK_SYM_W_SHIFT) | (start ? DTK_SYM_START : 0u);
     }
-    if (g0 + 4 <= total) {
-      *reinterpret_cast<uint2 *>(sym + g0) = make_uint2(out[0] | (out[1] << 16), out[2] | (out[3] << 16));
-    } else {
-      for (int j = 0; j < 4; j++)
-        if (g0 + j < total) sym[g0 + j] = (uint16_t)out[j];
-    }
+    __syncthreads();
   }
 }
 
@@ -880,24 +849,6 @@ __global__ __launch_bounds__(WAVE) void k_spec_clear(DtkWalkArgs A, DtkSpecArgs 
 }
 
 // ------------------------------------------------------------------ compact
-//
-// One wave per document.  Each iteration looks at 64 consecutive cursor
-// positions: lane i holds the event byte of position base+i, whether a rune
-// starts there, and the input byte.  Everything NewTokenWriter tracks
-// (token_writer.go:38-42: posC, pos, sentB, sent) is recovered with ballots,
-// popcounts of the lanes below, and a handful of shuffles; wave-uniform carries
-// link the tiles.  Order of the calls at one position = bit order of the byte.
-
-__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total) {
-  uint32_t x = v;
-#pragma unroll
-  for (int o = 1; o < WAVE; o <<= 1) {
-    uint32_t y = __shfl_up(x, o);
-    if ((int)lane_id() >= o) x += y;
-  }
-  total = __shfl(x, WAVE - 1);
-  return x - v;
-}
 
 #define CQ_CAP 512u  // ring capacity in events (power of two; one light tile adds at most 256)
 
@@ -1202,10 +1153,10 @@ extern "C" int dtk_launch_symbolize(const uint8_t *text, const uint64_t *doc_off
   // ALIGNED4 may read up to 3 bytes past `total`: true for the batch's own (padded) buffer;
   // a caller-owned device buffer only qualifies when its size is a multiple of 4
   if ((((uintptr_t)text) & 3u) == 0 && (padded || (total & 3u) == 0))
-    hipLaunchKernelGGL(k_symbolize<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, text, doc_off, n_docs,
+    hipLaunchKernelGGL(k_symbolize<true>, dim3(blocks), dim3(WAVE), 0, (hipStream_t)stream, text, doc_off, n_docs,
                        total, *sig, sym, blk_doc);
   else
-    hipLaunchKernelGGL(k_symbolize<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, text, doc_off, n_docs,
+    hipLaunchKernelGGL(k_symbolize<false>, dim3(blocks), dim3(WAVE), 0, (hipStream_t)stream, text, doc_off, n_docs,
                        total, *sig, sym, blk_doc);
   return (int)hipGetLastError();
 }
