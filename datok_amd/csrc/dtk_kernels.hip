@@ -81,6 +81,7 @@ __device__ __forceinline__ uint32_t doc_of(const uint64_t *__restrict__ doc_off,
 
 #define SYM_BLOCK_BYTES DTK_SYM_BLOCK_BYTES
 #define SYM_TILE 256u
+#define SYM_HALF 2048u  // the heavy pass runs once per this many bytes
 
 template <bool ALIGNED4>
 __global__ __launch_bounds__(WAVE) void k_symbolize(const uint8_t *__restrict__ text,
@@ -88,75 +89,108 @@ __global__ __launch_bounds__(WAVE) void k_symbolize(const uint8_t *__restrict__ 
                                                     uint32_t n_docs, uint64_t total, DtkSigmaDev sig,
                                                     uint16_t *__restrict__ sym,
                                                     const uint32_t *__restrict__ blk_doc) {
-  __shared__ uint16_t lut[256];       // symbol | class | START for runes < 128 (index = byte)
+  __shared__ uint16_t lut[128];       // symbol | class | START for the runes < 128 (index = byte)
   __shared__ uint16_t lat[256];       // symbol | class for runes < 256 (heavy path, Latin-1)
   __shared__ uint32_t s_runes[256];   // sigma map (runes >= 256)
   __shared__ uint16_t s_syms[256];
-  __shared__ uint16_t s_out[SYM_TILE];
-  __shared__ uint16_t s_q[SYM_TILE];  // queued positions (offset inside the tile)
+  __shared__ uint32_t s_txt[SYM_BLOCK_BYTES / 4 + 2];  // the block's bytes, one dword of halo either side
+  __shared__ uint16_t s_q[SYM_HALF];  // positions (offset in the block) of the bytes >= 0x80 of one half
   const uint32_t lane = threadIdx.x;
   const bool sig_lds = sig.n_runes <= 256u;
   for (uint32_t i = lane; i < 256u; i += WAVE) {
     // matrix.go:421-426: runes < 256 go through sigmaASCII; rune 4 is EOT
     const uint32_t e = (sig.ascii[i] & DTK_SYM_MASK) | (i == DTK_EOT ? (1u << DTK_SYM_CLS_SHIFT) : 0u);
     lat[i] = (uint16_t)e;
-    lut[i] = (uint16_t)(e | DTK_SYM_START);
+    if (i < 128u) lut[i] = (uint16_t)(e | DTK_SYM_START);
     if (sig_lds && i < sig.n_runes) { s_runes[i] = sig.runes[i]; s_syms[i] = sig.syms[i]; }
   }
-  __syncthreads();
   const uint64_t block_start = (uint64_t)blockIdx.x * SYM_BLOCK_BYTES;
+  const uint32_t n_here = (uint32_t)min((uint64_t)SYM_BLOCK_BYTES, total - block_start);
+  {
+    // all loads of the block are issued before anything waits for one of them
+    auto load4 = [&](uint64_t g) -> uint32_t {  // bytes g..g+3, zero outside [0, total)
+      if (ALIGNED4) return g < total ? *reinterpret_cast<const uint32_t *>(text + g) : 0u;
+      uint32_t x = 0;
+      for (int k = 0; k < 4; k++)
+        if (g + k < total) x |= (uint32_t)text[g + k] << (8 * k);
+      return x;
+    };
+    uint32_t v[SYM_BLOCK_BYTES / 4 / WAVE];
+#pragma unroll
+    for (uint32_t r = 0; r < SYM_BLOCK_BYTES / 4 / WAVE; r++) v[r] = load4(block_start + (r * WAVE + lane) * 4u);
+    uint32_t halo = 0;
+    if (lane == 0 && block_start >= 4) halo = load4(block_start - 4);
+    if (lane == 1) halo = load4(block_start + SYM_BLOCK_BYTES);
+#pragma unroll
+    for (uint32_t r = 0; r < SYM_BLOCK_BYTES / 4 / WAVE; r++) s_txt[1 + r * WAVE + lane] = v[r];
+    if (lane == 0) s_txt[0] = halo;
+    if (lane == 1) s_txt[1 + SYM_BLOCK_BYTES / 4] = halo;
+  }
+  __syncthreads();
+  const uint8_t *__restrict__ sb = reinterpret_cast<const uint8_t *>(s_txt) + 4;  // sb[i] = text[block_start + i]
+
   // documents that can own bytes of this block: host-computed (document of each block's
   // first byte), so no lane walks the offset table from scratch
   const uint32_t d_lo = blk_doc[blockIdx.x];
   const uint32_t d_hi = min(blk_doc[blockIdx.x + 1], n_docs - 1);
+  const uint64_t lo_start = doc_off[d_lo], lo_end = doc_off[d_lo + 1];  // the block's first document
+  const bool sym8 = ((reinterpret_cast<uintptr_t>(sym) + 2ull * block_start) & 7u) == 0;
 
 #pragma unroll 1
-  for (uint32_t it = 0; it < SYM_BLOCK_BYTES / SYM_TILE; it++) {
-    const uint64_t tile0 = block_start + (uint64_t)it * SYM_TILE;
-    if (tile0 >= total) break;
-    const uint64_t g0 = tile0 + lane * 4u;
-    // ---- light: 4 bytes per lane
-    uint32_t w = 0;
-    if (g0 < total) {
-      if (ALIGNED4) {
-        // the text buffer is padded (or a multiple of 4): a dword that straddles the end is readable
-        w = *reinterpret_cast<const uint32_t *>(text + g0);
+  for (uint32_t half = 0; half < SYM_BLOCK_BYTES / SYM_HALF; half++) {
+    if (half * SYM_HALF >= n_here) break;
+    // ---- light: every byte < 0x80 is a complete rune: its entry goes straight to memory
+    //      (8-byte stores); the positions of the other bytes are queued
+    uint32_t nq = 0;  // wave-uniform
+#pragma unroll 1
+    for (uint32_t it = 0; it < SYM_HALF / SYM_TILE; it++) {
+      const uint32_t i0 = half * SYM_HALF + it * SYM_TILE + lane * 4u;  // my 4 bytes (offset in the block)
+      if (half * SYM_HALF + it * SYM_TILE >= n_here) break;
+      const uint32_t w = s_txt[1 + (i0 >> 2)];
+      const uint32_t e0 = lut[w & 0x7Fu], e1 = lut[(w >> 8) & 0x7Fu];
+      const uint32_t e2 = lut[(w >> 16) & 0x7Fu], e3 = lut[(w >> 24) & 0x7Fu];
+      const uint32_t left = i0 < n_here ? (n_here - i0 >= 4u ? 4u : n_here - i0) : 0u;
+      if (left == 4u && sym8) {
+        *reinterpret_cast<uint2 *>(sym + block_start + i0) = make_uint2(e0 | (e1 << 16), e2 | (e3 << 16));
       } else {
-        for (int k = 0; k < 4; k++)
-          if (g0 + k < total) w |= (uint32_t)text[g0 + k] << (8 * k);
+        const uint32_t o[4] = {e0, e1, e2, e3};
+        for (uint32_t j = 0; j < left; j++) sym[block_start + i0 + j] = (uint16_t)o[j];
+      }
+      const uint32_t hib = (w & 0x80808080u) & (left >= 4u ? 0xFFFFFFFFu : ((1u << (8u * left)) - 1u));
+      if (__ballot(hib != 0u) != 0ull) {
+        const uint32_t rare = ((hib >> 7) & 1u) | ((hib >> 14) & 2u) | ((hib >> 21) & 4u) | ((hib >> 28) & 8u);
+        uint32_t tot;
+        uint32_t slot = nq + wave_excl_scan((uint32_t)__popc(rare), tot);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (rare & (1u << j)) s_q[slot++] = (uint16_t)(i0 + j);
+        nq += tot;
       }
     }
-    const uint32_t left = g0 < total ? (total - g0 >= 4 ? 4u : (uint32_t)(total - g0)) : 0u;
-    const uint32_t hib = (w & 0x80808080u) & (left >= 4 ? 0xFFFFFFFFu : ((1u << (8u * left)) - 1u));
-    const uint32_t rare = ((hib >> 7) & 1u) | ((hib >> 14) & 2u) | ((hib >> 21) & 4u) | ((hib >> 28) & 8u);
-    s_out[lane * 4u + 0u] = lut[w & 0x7Fu];
-    s_out[lane * 4u + 1u] = lut[(w >> 8) & 0x7Fu];
-    s_out[lane * 4u + 2u] = lut[(w >> 16) & 0x7Fu];
-    s_out[lane * 4u + 3u] = lut[(w >> 24) & 0x7Fu];
-    uint32_t nq;
-    uint32_t slot = wave_excl_scan((uint32_t)__popc(rare), nq);
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-      if (rare & (1u << j)) s_q[slot++] = (uint16_t)(lane * 4u + j);
+    if (nq == 0) continue;
+    // the heavy lanes overwrite single entries written above: those stores must have landed
+    __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) lgkmcnt(0): stores count in vmcnt on gfx950
     __syncthreads();
 
     // ---- heavy: one queued position per lane
     for (uint32_t q0 = 0; q0 < nq; q0 += WAVE) {
       if (q0 + lane < nq) {
         const uint32_t pos = s_q[q0 + lane];
-        const uint64_t g = tile0 + pos;
-        // my document
-        uint32_t d = d_lo == d_hi ? d_lo : doc_of(doc_off, d_lo, d_hi + 1, g);
-        const uint64_t dstart = doc_off[d], dend = doc_off[d + 1];
+        const uint64_t g = block_start + pos;
+        uint64_t dstart = lo_start, dend = lo_end;
+        if (g >= lo_end) {  // a later document of this block
+          const uint32_t d = doc_of(doc_off, d_lo, d_hi + 1, g);
+          dstart = doc_off[d]; dend = doc_off[d + 1];
+        }
         const uint64_t l64 = dend - g, b64 = g - dstart;
         const uint32_t avail = l64 > 8 ? 8u : (uint32_t)l64, back = b64 > 3 ? 3u : (uint32_t)b64;
-        // bytes g-3 .. g+3 (inside the document; the tile was just read, these hit in cache)
+        // bytes g-3 .. g+3 (inside the document), from the staged block
         uint32_t bb[7];
 #pragma unroll
         for (int k = 0; k < 7; k++) {
           const int o = k - 3;
           const bool in = o < 0 ? (uint32_t)(-o) <= back : (uint32_t)o < avail;
-          bb[k] = in ? (uint32_t)text[g + o] : 0u;
+          bb[k] = in ? (uint32_t)sb[(int)pos + o] : 0u;
         }
         const uint32_t b0 = bb[3], b1 = bb[4], b2 = bb[5], b3 = bb[6];
         const uint32_t wd = go_width(b0, b1, b2, b3, avail);
@@ -196,24 +230,10 @@ __global__ __launch_bounds__(WAVE) void k_symbolize(const uint8_t *__restrict__ 
             if (r < rune) l = m + 1; else h = m - 1;
           }
         }
-        s_out[pos] = (uint16_t)(a_cls | ((wd - 1) << DTK_SYM_W_SHIFT) | (start ? DTK_SYM_START : 0u));
+        sym[g] = (uint16_t)(a_cls | ((wd - 1) << DTK_SYM_W_SHIFT) | (start ? DTK_SYM_START : 0u));
       }
     }
-    __syncthreads();
-
-    // ---- store the tile
-    if (g0 < total) {
-      const uint32_t o01 = *reinterpret_cast<const uint32_t *>(&s_out[lane * 4u]);
-      const uint32_t o23 = *reinterpret_cast<const uint32_t *>(&s_out[lane * 4u + 2u]);
-      if (g0 + 4 <= total) {
-        *reinterpret_cast<uint2 *>(sym + g0) = make_uint2(o01, o23);
-      } else {
-        const uint32_t o[4] = {o01 & 0xFFFFu, o01 >> 16, o23 & 0xFFFFu, o23 >> 16};
-        for (int j = 0; j < 4; j++)
-          if (g0 + j < total) sym[g0 + j] = (uint16_t)o[j];
-      }
-    }
-    __syncthreads();
+    __syncthreads();  // the queue is reused by the next half
   }
 }
 
