@@ -8,7 +8,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdatok_gpu.so")
+# DATOK_GPU_LIB selects another build of the same library (A/B timing on one box)
+LIB_PATH = os.environ.get("DATOK_GPU_LIB") or os.path.join(_HERE, "libdatok_gpu.so")
 
 # error codes / flags (datok_gpu.h)
 OK, E_IO, E_FORMAT, E_NO_DEVICE, E_HIP, E_ARG, E_MODEL, E_CAPACITY, E_STATE = 0, -1, -2, -3, -4, -5, -6, -7, -8
