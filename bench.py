@@ -141,12 +141,9 @@ def main():
     # ---- offset gather to rank 0 over RCCL (config 5's exchange), outside the clock
     gather_ms = None
     if world > 1:
+        from datok_amd import shard
         v = batch.result_device()
         ntok, nsent = tot["n_tokens"], tot["n_sent"]
-        counts = torch.tensor([ntok, nsent], dtype=torch.int64, device=dev)
-        allc = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(allc, counts)
-        allc = torch.stack(allc).cpu().numpy()
 
         class _DevI32:  # zero-copy view of a library-owned device array
             def __init__(self, ptr, n):
@@ -156,22 +153,19 @@ def main():
         def dev_i32(ptr, n):
             if n == 0:
                 return torch.empty(0, dtype=torch.int32, device=dev)
-            return torch.as_tensor(_DevI32(ptr, n), device=dev)
-        mine = torch.cat([dev_i32(v.tok_rstart, ntok), dev_i32(v.tok_rend, ntok), dev_i32(v.sent, nsent)])
+            return torch.as_tensor(_DevI32(ptr, n), device=dev).clone()
+        mine = {"tok_rstart": dev_i32(v.tok_rstart, ntok), "tok_rend": dev_i32(v.tok_rend, ntok),
+                "sent": dev_i32(v.sent, nsent)}
         torch.cuda.synchronize()
         dist.barrier()
         g0 = time.perf_counter()
-        if rank == 0:
-            recv = [torch.empty(int(2 * allc[r, 0] + allc[r, 1]), dtype=torch.int32, device=dev)
-                    for r in range(1, world)]
-            reqs = [dist.irecv(recv[r - 1], src=r) for r in range(1, world)]
-            for q in reqs:
-                q.wait()
-        else:
-            dist.send(mine, dst=0)
+        got = shard.gather_offsets(mine, rank, world, dist, device=dev)
         torch.cuda.synchronize()
         dist.barrier()
         gather_ms = (time.perf_counter() - g0) * 1e3
+        if rank == 0:
+            assert sum(int(t.numel()) for t in got["tok_rstart"]) >= ntok
+        del got
 
     # ---- CPU baseline: the C restatement of the Go algorithm, rank 0, N = 1 only
     cpu = None
@@ -202,6 +196,16 @@ def main():
         b_alg = total + 4 * (args.docs + 1) + 4 * (2 * tot["n_tokens"] + tot["n_sent"]) + 8 * args.docs
         walk_s = stage_avg["walk"] * 1e-3
         achieved = b_alg / walk_s / 1e9
+        both_s = (stage_avg["walk"] + stage_avg["spec_start"]) * 1e-3
+        # HBM bytes of that kernel from the last committed rocprofv3 --pmc passes (profiles/)
+        traffic = None
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            if tr.get("docs") == args.docs and tr.get("doc_bytes") == args.doc_bytes and \
+                    tr.get("chunk_bytes") == tot["chunk_bytes"]:
+                traffic = tr["walk_kernel_hbm_bytes"]
+        except (OSError, ValueError, KeyError):
+            pass
         out = {
             "metric": "input MB/s tokenized, tokenizer_de.matok",
             "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": args.steps,
@@ -211,13 +215,15 @@ def main():
                                    "(BASELINE.json configs[1])" % (args.docs, args.doc_bytes),
                        "docs_per_gpu": args.docs, "doc_bytes": args.doc_bytes,
                        "parallelism": "documents sharded over %d GPU(s), no data-path collective" % world},
-            "roofline": {"bound": "hbm", "kernel": "k_walk<MatrixTrans<u16>>", "achieved": round(achieved, 2),
+            "roofline": {"bound": "hbm",
+                         "kernel": "k_spec_walk<MatrixTrans<u16>>" if tot["chunk_bytes"] else "k_walk_doc<MatrixTrans<u16>>",
+                         "achieved": round(achieved, 2),
                          "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 6),
-                         "traffic": None, "algorithmic_bytes": int(b_alg),
+                         "traffic": traffic, "algorithmic_bytes": int(b_alg),
                          "kernel_ms": round(stage_avg["walk"], 4),
                          "lookups_per_launch": int(tot["walk_steps"]),
-                         "Glookups_per_s": round(tot["walk_steps"] / walk_s / 1e9, 3)},
-            "stages_ms": {k: round(v, 4) for k, v in stage_avg.items() if k != "unused"},
+                         "Glookups_per_s_start_plus_walk": round(tot["walk_steps"] / both_s / 1e9, 3)},
+            "stages_ms": {k: round(v, 4) for k, v in stage_avg.items()},
             "tokens_per_launch": int(tot["n_tokens"]),
             "walk": {"lanes": int(tot["n_lanes"]), "chunk_bytes": int(tot["chunk_bytes"]), "warm_bytes": args.warm,
                      "repair_rounds": int(tot["repair_rounds"])},

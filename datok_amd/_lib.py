@@ -108,7 +108,7 @@ def lib():
     L.dtk_batch_totals.argtypes = [vp, C.POINTER(Totals)]
     L.dtk_batch_set_chunking.argtypes = [vp, u32, u32]
     L.dtk_batch_set_profiling.argtypes = [vp, C.c_int]
-    L.dtk_batch_stage_ms.argtypes = [vp, C.POINTER(C.c_float * 6)]
+    L.dtk_batch_stage_ms.argtypes = [vp, C.POINTER(C.c_float * 9)]
     L.dtk_batch_result_device.argtypes = [vp, C.POINTER(ResultView)]
     L.dtk_batch_result_host.argtypes = [vp, C.POINTER(ResultView)]
     L.dtk_transduce.argtypes = [vp, C.c_char_p, sz, u32, C.POINTER(vp), C.POINTER(sz), C.POINTER(u32)]

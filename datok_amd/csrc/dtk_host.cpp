@@ -448,7 +448,7 @@ struct dtk_batch {
   uint32_t *d_bstart = nullptr, *d_bend = nullptr, *d_ttok = nullptr, *d_tsent = nullptr;
   // optional stage timing
   bool profiling = false;
-  hipEvent_t ev[7] = {};
+  hipEvent_t ev[DTK_N_STAGES + 1] = {};
   // last run
   bool ran = false, totals_valid = false;
   DtkCompactArgs last_args{};
@@ -740,15 +740,18 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
   STAGE(2);
   DtkWalkArgs w = walk_args(b);
   if (b->chunk == 0) {
+    STAGE(3); STAGE(4);
     if (dtk_launch_walk(&m->tab, &w, s)) return hip_fail(hipGetLastError(), "walk");
+    STAGE(5); STAGE(6); STAGE(7);
   } else {
     DtkSpecArgs sp = spec_args(b, false);
     uint32_t *n_bad = (uint32_t *)(b->d_totals + 5);
-    for (int stage = 0; stage < 5; stage++)
+    for (int stage = 0; stage < 5; stage++) {
       if (dtk_launch_spec(&m->tab, &w, &sp, stage, cmp_mask_of(m), b->d_redo, n_bad, s))
         return hip_fail(hipGetLastError(), "speculative walk");
+      STAGE(3 + stage);  // ends: start records, link, chunk walk, verify, fix
+    }
   }
-  STAGE(3);
   DtkCompactArgs c{};
   c.text = b->d_text; c.sym = b->d_sym; c.doc_off = b->d_off; c.n_docs = b->n_docs;
   c.evA = b->d_evA; c.evB = b->d_evB; c.tlen = b->d_tlen; c.status = b->d_status;
@@ -756,15 +759,14 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
   c.tok_off = b->d_tok_off; c.sent_off = b->d_sent_off; c.text_off = b->d_text_off;
   c.totals = b->d_totals;
   // rows are sized by the walk's own counts (no counting pass)
-  STAGE(4);
   if (dtk_launch_scan3(b->d_tok_cnt, b->d_sent_cnt, b->d_text_cnt, b->d_tok_off, b->d_sent_off, b->d_text_off,
                        b->n_docs, b->d_totals, b->d_status, s))
     return hip_fail(hipGetLastError(), "scan");
-  STAGE(5);
+  STAGE(8);
   b->last_args = c;
   int rc = launch_compact2(b);
   if (rc != DTK_OK) return rc;
-  STAGE(6);
+  STAGE(9);
 #undef STAGE
   HIP_TRY(hipMemcpyAsync(b->h_totals, b->d_totals, 8 * 8, hipMemcpyDeviceToHost, s));
   b->ran = true;
@@ -780,11 +782,11 @@ extern "C" int dtk_batch_set_profiling(dtk_batch *b, int enable) {
   return DTK_OK;
 }
 
-extern "C" int dtk_batch_stage_ms(dtk_batch *b, float ms[6]) {
+extern "C" int dtk_batch_stage_ms(dtk_batch *b, float ms[DTK_N_STAGES]) {
   if (!b || !ms) return DTK_E_ARG;
   if (!b->ran || !b->profiling) return DTK_E_STATE;
   HIP_TRY(hipStreamSynchronize(b->stream));
-  for (int i = 0; i < 6; i++) HIP_TRY(hipEventElapsedTime(&ms[i], b->ev[i], b->ev[i + 1]));
+  for (int i = 0; i < DTK_N_STAGES; i++) HIP_TRY(hipEventElapsedTime(&ms[i], b->ev[i], b->ev[i + 1]));
   return DTK_OK;
 }
 

@@ -308,11 +308,11 @@ class Batch:
     def set_profiling(self, enable=True):
         check(lib().dtk_batch_set_profiling(self._h, int(bool(enable))), "dtk_batch_set_profiling")
 
-    STAGES = ("clear", "symbolize", "walk", "unused", "scan", "compact")
+    STAGES = ("clear", "symbolize", "spec_start", "spec_link", "walk", "spec_verify", "spec_fix", "scan", "compact")
 
     def stage_ms(self):
         """Milliseconds per stage of the last run (needs set_profiling(True))."""
-        ms = (C.c_float * 6)()
+        ms = (C.c_float * 9)()
         check(lib().dtk_batch_stage_ms(self._h, C.byref(ms)), "dtk_batch_stage_ms")
         return dict(zip(self.STAGES, [float(x) for x in ms]))
 

@@ -127,10 +127,11 @@ void *dtk_batch_stream(dtk_batch *b); /* hipStream_t, for event timing by the ca
 /* Optional per-stage timing with HIP events recorded on the batch's stream
  * around each kernel of dtk_batch_run (no host synchronisation is added).
  * dtk_batch_stage_ms() synchronises and returns the milliseconds of the last
- * run: [0] clears [1] symbolise [2] walk (start records, link, chunk walk,
- * verify, fix) [3] unused [4] scan [5] compaction. */
+ * run: [0] clears [1] symbolise [2] start records [3] link [4] chunk walk (or
+ * the one-lane-per-document walk) [5] verify [6] fix [7] scan [8] compaction. */
+#define DTK_N_STAGES 9
 int dtk_batch_set_profiling(dtk_batch *b, int enable);
-int dtk_batch_stage_ms(dtk_batch *b, float ms[6]);
+int dtk_batch_stage_ms(dtk_batch *b, float ms[DTK_N_STAGES]);
 
 /* Totals of the last run (synchronises). */
 typedef struct {

@@ -1,0 +1,63 @@
+"""The C-ABI library loads and exports every symbol include/datok_gpu.h declares.
+No compute call is made here (no GPU in the CPU test tier)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "datok_gpu.h"), encoding="utf-8").read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dtk_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_builds_and_exports_the_header():
+    import datok_amd
+    path = datok_amd.build()
+    lib = ctypes.CDLL(path)
+    names = declared_symbols()
+    assert len(names) >= 24
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    # the Python binding knows every export too
+    from datok_amd import _lib
+    assert sorted(_lib.EXPORTS) == names
+
+
+def test_no_cpu_fallback_without_a_device():
+    """On a box without a HIP device the product path must fail loudly, never fall back."""
+    import datok_amd
+    from datok_amd import _lib
+    L = datok_amd.lib()
+    if L.dtk_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(_lib.DatokGpuError) as e:
+        datok_amd.load_tokenizer_file(os.path.join(ROOT, "tests", "golden", "models", "simpletok.matok"))
+    assert e.value.code == _lib.E_NO_DEVICE
+    with pytest.raises(_lib.DatokGpuError):
+        datok_amd.Batch(1024, 4)
+    assert b"no CPU path" in L.dtk_strerror(_lib.E_NO_DEVICE)
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under datok_amd/ or include/ may reference it."""
+    for base in ("datok_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp", "Makefile")):
+                    txt = open(os.path.join(dirpath, f), encoding="utf-8", errors="replace").read()
+                    assert "liboracle" not in txt and "datok_oracle" not in txt, os.path.join(dirpath, f)
+                    assert not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M), os.path.join(dirpath, f)
+
+
+def test_error_strings_and_constants():
+    import datok_amd
+    L = datok_amd.lib()
+    for code in range(0, -9, -1):
+        assert L.dtk_strerror(code)
+    assert (datok_amd.TOKENS, datok_amd.SENTENCES, datok_amd.TOKEN_POS, datok_amd.SENTENCE_POS,
+            datok_amd.NEWLINE_AFTER_EOT, datok_amd.SIMPLE) == (1, 2, 4, 8, 16, 3)   # token_writer.go:17-25
