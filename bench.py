@@ -86,7 +86,6 @@ def main():
     batch.set_chunking(datok_amd.Batch.AUTO_CHUNK if args.chunk < 0 else args.chunk, args.warm)
     batch.set_input_device(t_text.data_ptr(), t_off.data_ptr(), args.docs, total,
                            keep=(t_text, t_off), doc_off_host=doc_off)
-    stream = torch.cuda.ExternalStream(batch.stream, device=dev)
 
     # ---- parity gate (oracle is the checker, never the thing measured)
     batch.run(tok, 0)
@@ -159,13 +158,17 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
         g0 = time.perf_counter()
-        got = shard.gather_offsets(mine, rank, world, dist, device=dev)
-        torch.cuda.synchronize()
+        try:
+            got = shard.gather_offsets(mine, rank, world, dist, device=dev)
+            torch.cuda.synchronize()
+            gather_ms = (time.perf_counter() - g0) * 1e3
+            if rank == 0:
+                assert sum(int(t.numel()) for t in got["tok_rstart"]) >= ntok
+            del got
+        except Exception as e:  # the gather is outside the timed region: report, do not lose the run
+            print("bench.py: offset gather failed on rank %d: %r" % (rank, e), file=sys.stderr)
+            gather_ms = None
         dist.barrier()
-        gather_ms = (time.perf_counter() - g0) * 1e3
-        if rank == 0:
-            assert sum(int(t.numel()) for t in got["tok_rstart"]) >= ntok
-        del got
 
     # ---- CPU baseline: the C restatement of the Go algorithm, rank 0, N = 1 only
     cpu = None
