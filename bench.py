@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--doc-bytes", type=int, default=4096)
     ap.add_argument("--model", default=MODEL)
     ap.add_argument("--chunk", type=int, default=-1, help="-1 automatic, 0 one lane per document, else bytes")
-    ap.add_argument("--warm", type=int, default=64)
+    ap.add_argument("--warm", type=int, default=48)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--parity-docs", type=int, default=256, help="documents checked against the oracle before timing")

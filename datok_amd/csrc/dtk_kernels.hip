@@ -764,30 +764,48 @@ __global__ __launch_bounds__(WAVE) void k_spec_walk(TRANS tr, DtkWalkArgs A, Dtk
 // first lane that did not is recorded (bit-inverted, zero = none) in fail_lane[d].
 __global__ __launch_bounds__(256) void k_spec_verify(DtkWalkArgs A, DtkSpecArgs S, uint32_t cmp_mask) {
   const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
-  if (L >= S.n_lanes) return;
-  const uint32_t d = S.lane_doc[L];
-  const uint32_t L0 = S.chunk_off[d];
-  const uint32_t k = L - L0, fb = ~S.first_bad[d];
-  if (k > fb) {
-    // a lane behind the chain: legitimate only if the chain ran to EOF and I found no sync point
-    if (S.lane_start[L].p != 0xFFFFFFFFu) atomicMax(&S.fail_lane[d], ~(L0 + fb));
-    return;
+  const bool live = L < S.n_lanes;  // every lane stays for the wave reduction below
+  uint32_t d = 0xFFFFFFFFu;
+  DtkLaneCount c{0u, 0u, 0u, 0u};
+  if (live) {
+    d = S.lane_doc[L];
+    const uint32_t L0 = S.chunk_off[d];
+    const uint32_t k = L - L0, fb = ~S.first_bad[d];
+    if (k > fb) {
+      // a lane behind the chain: legitimate only if the chain ran to EOF and I found no sync point
+      if (S.lane_start[L].p != 0xFFFFFFFFu) atomicMax(&S.fail_lane[d], ~(L0 + fb));
+    } else {
+      const DtkLaneState en = S.lane_end[L];
+      bool good;
+      if (k < fb) {
+        const DtkLaneState nx = S.lane_start[L + 1];
+        good = en.p == nx.p && en.t == nx.t && ((en.flags ^ nx.flags) & cmp_mask) == 0 &&
+               !(en.flags & LANE_F_DROPPED);
+      } else {
+        good = en.p == 0xFFFFFFFFu && !(en.flags & LANE_F_IDLE);  // the chain's last lane must reach EOF
+      }
+      if (good) c = S.lane_cnt[L]; else atomicMax(&S.fail_lane[d], ~L);
+    }
   }
-  const DtkLaneState en = S.lane_end[L];
-  bool good;
-  if (k < fb) {
-    const DtkLaneState nx = S.lane_start[L + 1];
-    good = en.p == nx.p && en.t == nx.t && ((en.flags ^ nx.flags) & cmp_mask) == 0 &&
-           !(en.flags & LANE_F_DROPPED);
-  } else {
-    good = en.p == 0xFFFFFFFFu && !(en.flags & LANE_F_IDLE);  // the chain's last lane must reach EOF
+  // The lanes of a document are consecutive: add up the counts of each run of equal
+  // documents inside the wave, then one atomic per run instead of one per lane.
+  uint32_t tok = c.tok, sent = c.sent, text = c.text, st = c.status;
+#pragma unroll
+  for (int o = 1; o < WAVE; o <<= 1) {
+    const uint32_t dn = __shfl_down(d, o);
+    const uint32_t t2 = __shfl_down(tok, o), s2 = __shfl_down(sent, o), x2 = __shfl_down(text, o),
+                   st2 = __shfl_down(st, o);
+    const bool same = (lane_id() + o < WAVE) && dn == d;
+    tok += same ? t2 : 0u; sent += same ? s2 : 0u; text += same ? x2 : 0u; st |= same ? st2 : 0u;
   }
-  if (!good) { atomicMax(&S.fail_lane[d], ~L); return; }
-  const DtkLaneCount c = S.lane_cnt[L];
-  if (c.tok) atomicAdd((unsigned long long *)&A.tok_cnt[d], (unsigned long long)c.tok);
-  if (c.sent) atomicAdd((unsigned long long *)&A.sent_cnt[d], (unsigned long long)c.sent);
-  if (c.text) atomicAdd((unsigned long long *)&A.text_cnt[d], (unsigned long long)c.text);
-  if (c.status) atomicOr(&A.status[d], c.status);
+  const uint32_t dprev = __shfl_up(d, 1);
+  const bool head = live && (lane_id() == 0 || dprev != d);
+  if (head) {
+    if (tok) atomicAdd((unsigned long long *)&A.tok_cnt[d], (unsigned long long)tok);
+    if (sent) atomicAdd((unsigned long long *)&A.sent_cnt[d], (unsigned long long)sent);
+    if (text) atomicAdd((unsigned long long *)&A.text_cnt[d], (unsigned long long)text);
+    if (st) atomicOr(&A.status[d], st);
+  }
 }
 
 // One thread per document: nothing to do unless a lane failed; then the lane

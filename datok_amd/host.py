@@ -301,7 +301,7 @@ class Batch:
 
     AUTO_CHUNK = 0xFFFFFFFF
 
-    def set_chunking(self, chunk_bytes=AUTO_CHUNK, warm_bytes=64):
+    def set_chunking(self, chunk_bytes=AUTO_CHUNK, warm_bytes=48):
         """0: one lane per document; otherwise speculative chunk lanes (exact either way)."""
         check(lib().dtk_batch_set_chunking(self._h, int(chunk_bytes), int(warm_bytes)), "dtk_batch_set_chunking")
 
