@@ -247,7 +247,15 @@ static int build_matrix(dtk_model *m, const std::vector<uint8_t> &raw) {
   const bool wide = (N + 1) > 0x7FFFu;
   const uint32_t stride = (uint32_t)((S + 7) & ~7ull);
   const size_t cells_total = (size_t)(N + 1) * stride;
-  std::vector<uint8_t> host(cells_total * (wide ? 4 : 2), 0);
+  // 15-bit state ids: uint32 cells with fused epsilon+rune entries (MatrixFusedTrans);
+  // DATOK_NO_FUSED=1 keeps the plain uint16 table (for A/B measurements)
+  const bool fused = !wide && !getenv("DATOK_NO_FUSED");
+  const size_t cell_bytes = (wide || fused) ? 4 : 2;
+  std::vector<uint8_t> host(cells_total * cell_bytes, 0);
+  auto put = [&](size_t at, uint32_t v) {
+    if (cell_bytes == 4) memcpy(host.data() + at * 4, &v, 4);
+    else { uint16_t h = (uint16_t)v; memcpy(host.data() + at * 2, &h, 2); }
+  };
   for (uint64_t a = 1; a < S; a++) {
     for (uint64_t t = 1; t <= N; t++) {
       const uint32_t x = cell(a, t);
@@ -256,17 +264,30 @@ static int build_matrix(dtk_model *m, const std::vector<uint8_t> &raw) {
       if (tgt > N) return DTK_E_MODEL;
       if ((int)a == m->unknown) m->unknown_used = 1;
       const size_t at = (size_t)newid[t] * stride + a;
-      if (wide) {
-        uint32_t v = newid[tgt] | (x & DTK_FIRSTBIT);
-        memcpy(host.data() + at * 4, &v, 4);
-      } else {
-        uint16_t v = (uint16_t)(newid[tgt] | ((x & DTK_FIRSTBIT) ? 0x8000u : 0u));
-        memcpy(host.data() + at * 2, &v, 2);
+      if (wide) put(at, newid[tgt] | (x & DTK_FIRSTBIT));
+      else put(at, newid[tgt] | ((x & DTK_FIRSTBIT) ? 0x8000u : 0u));
+    }
+  }
+  if (fused) {
+    // (t, a) empty, t --epsilon--> e, (e, a) present:  1<<31 | e<<16 | cell(e, a)
+    for (uint64_t t = 1; t <= N; t++) {
+      const uint32_t e = cell((uint64_t)m->epsilon, t) & ~DTK_FIRSTBIT;
+      if (e == 0 || e > N) continue;
+      for (uint64_t a = 1; a < S; a++) {
+        if ((int)a == m->epsilon || (int)a == m->unknown) continue;
+        if ((cell(a, t) & ~DTK_FIRSTBIT) != 0) continue;
+        const uint32_t x2 = cell(a, e);
+        const uint32_t tgt2 = x2 & ~DTK_FIRSTBIT;
+        if (tgt2 == 0 || tgt2 > N) continue;
+        put((size_t)newid[t] * stride + a,
+            0x80000000u | (newid[e] << 16) | newid[tgt2] | ((x2 & DTK_FIRSTBIT) ? 0x8000u : 0u));
       }
     }
   }
   m->tab.kind = DTK_KIND_MATRIX;
-  m->tab.entry_bytes = wide ? 4 : 2;
+  m->tab.entry_bytes = (uint32_t)cell_bytes;
+  m->tab.fused = fused ? 1u : 0u;
+  m->tab.ident_guard = m->unknown_used ? (uint32_t)m->identity : 0xFFFFFFFFu;
   m->tab.stride = stride;
   m->tab.n_states = (uint32_t)N;
   m->tab.n_eps = m->n_eps_states;

@@ -247,13 +247,15 @@ struct MatrixTrans {
   const CELL *tab;
   uint32_t stride, n_eps, start;
   static constexpr CELL FLAG = (CELL)((CELL)1 << (sizeof(CELL) * 8 - 1));
+  static constexpr bool FUSED = false;
   __device__ __forceinline__ uint32_t start_state() const { return start; }
   __device__ __forceinline__ uint32_t start_aux() const { return 0; }
   // matrix.go:442 `array[(epsilon-1)*stateCount+t0] != 0` after renumbering
   __device__ __forceinline__ bool has_eps(uint32_t t, uint32_t) const { return t <= n_eps; }
   // matrix.go:459-464; column 0 is zero so a == 0 fails without a branch
   __device__ __forceinline__ bool step(uint32_t t0, uint32_t, uint32_t a, uint32_t &t,
-                                       uint32_t &aux, bool &nontoken, uint32_t &st) const {
+                                       uint32_t &aux, bool &nontoken, uint32_t &st, uint32_t &via) const {
+    via = 0;
     const CELL x = tab[(size_t)t0 * stride + a];
     t = (uint32_t)(x & (CELL)~FLAG);  // matrix.go:629 t &= ^FIRSTBIT
     nontoken = (x & FLAG) != 0;       // matrix.go:584
@@ -263,9 +265,36 @@ struct MatrixTrans {
   }
 };
 
+// Matrix with fused cells (uint32): where state t has an epsilon arc to e and no arc on
+// symbol a, but e has one, the cell (t, a) holds  1<<31 | e<<16 | cell(e, a).  The walk then
+// does in one lookup what the reference does in three (matrix.go:472-497 fail + backtrack to
+// the state remembered at this very rune, :563-576 epsilon step, :579-591 the rune from e).
+// Only built when state ids fit 15 bits.
+struct MatrixFusedTrans {
+  const uint32_t *tab;
+  uint32_t stride, n_eps, start;
+  uint32_t ident_guard;  // the identity symbol if the model has arcs on `unknown`, else no symbol
+  static constexpr bool FUSED = true;
+  __device__ __forceinline__ uint32_t start_state() const { return start; }
+  __device__ __forceinline__ uint32_t start_aux() const { return 0; }
+  __device__ __forceinline__ bool has_eps(uint32_t t, uint32_t) const { return t <= n_eps; }
+  // via: 0, or the epsilon target e the fused cell goes through
+  __device__ __forceinline__ bool step(uint32_t t0, uint32_t, uint32_t a, uint32_t &t, uint32_t &aux,
+                                       bool &nontoken, uint32_t &st, uint32_t &via) const {
+    const uint32_t x = tab[(size_t)t0 * stride + a];
+    t = x & 0x7FFFu;
+    nontoken = (x & 0x8000u) != 0;
+    via = x >> 31 ? (x >> 16) & 0x7FFFu : 0u;
+    aux = 0;
+    (void)st;
+    return t != 0;
+  }
+};
+
 struct DaTrans {
   const uint2 *arr;  // .x base (bit31 separate, bit30 has-epsilon cache), .y check
   uint32_t len, size, base1;
+  static constexpr bool FUSED = false;
   __device__ __forceinline__ uint32_t start_state() const { return 1u; }  // datok.go:784
   __device__ __forceinline__ uint32_t start_aux() const { return base1; }
   // datok.go:876, precomputed per index at load
@@ -274,7 +303,8 @@ struct DaTrans {
   }
   // datok.go:889-901 and :1056-1058
   __device__ __forceinline__ bool step(uint32_t t0, uint32_t aux0, uint32_t a, uint32_t &t,
-                                       uint32_t &aux, bool &nontoken, uint32_t &st) const {
+                                       uint32_t &aux, bool &nontoken, uint32_t &st, uint32_t &via) const {
+    via = 0;
     const uint32_t idx = (aux0 & DTK_RESTBIT) + a;
     if (idx >= len) { st |= ST_BAD_MODEL; return false; }  // Go: index panic
     const uint2 ta = arr[idx];
@@ -373,6 +403,11 @@ struct EventSink {
     evB[p] = (uint8_t)(bits | (p == last_s_p ? s_bits : 0u));
   }
 };
+
+template <typename TRANS>
+__device__ __forceinline__ uint32_t guard_of(const TRANS &tr) {
+  if constexpr (TRANS::FUSED) return tr.ident_guard; else return 0xFFFFFFFFu;
+}
 
 // What a lane is asked to do.
 enum { MODE_DOC = 0,    // whole document from the initial state, all events
@@ -473,18 +508,31 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
     }
 
     bool nontoken = false;
-    const bool good = tr.step(t0, aux0, a, t, aux, nontoken, st);  // a finished lane looks up harmlessly
+    uint32_t via = 0;
+    const bool fresh = newchar;  // this lookup is the first one for the rune at p
+    bool good = tr.step(t0, aux0, a, t, aux, nontoken, st, via);  // a finished lane looks up harmlessly
     const bool act = !done;
     my_steps += act ? 1u : 0u;
     const bool is_eps = a == epsilon;
-    const bool succ = act && good, fail = act && !good;
+    // A fused cell stands for: this rune has no arc here, the epsilon state remembered at this
+    // very rune is t0 itself (matrix.go:442-454), take its epsilon arc to `via`, then the rune
+    // from there.  Not taken where the reference would first retry with the unknown symbol
+    // (matrix.go:478-485; only observable if the model has such arcs), nor where the rewind
+    // would end this lane's chunk (the plain path then stops at the rewind).
+    bool comp = false;
+    if (TRANS::FUSED) {
+      comp = act && good && via != 0 && fresh && !(!ok && a == guard_of(tr)) &&
+             !(MODE != MODE_DOC && p >= stop_pos);
+      good = good && (via == 0 || comp);
+    }
+    const bool succ = act && good && !comp, fail = act && !good;
     const bool retry_unknown = fail && !ok && a == identity;               // matrix.go:478-485
     const bool backtrack = fail && !retry_unknown && !is_eps && eps_t != 0;   // matrix.go:487-497
     bool hardfail = fail && !retry_unknown && !backtrack;                  // matrix.go:499-552
     const bool flush_eps = succ && is_eps && p > tp;                       // matrix.go:565-572
     const bool sent_eps = succ && is_eps && p <= tp;                       // matrix.go:573-576
     const bool advance = succ && !is_eps;                                  // matrix.go:579-591
-    const bool eot_now = advance && eot;                                   // matrix.go:593-605
+    const bool eot_now = (advance || comp) && eot;                         // matrix.go:593-605
 
     if (hardfail || my_steps > cap) {  // rare
       if (hardfail) {  // drop what is buffered as a token, restart at state 1
@@ -494,39 +542,50 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
       }
       if (my_steps > cap) { st |= ST_STEP_LIMIT; done = true; hardfail = false; }
     }
-    const bool flush = flush_eps || hardfail;
+    const bool flush_c = comp && p > tp, sent_c = comp && p <= tp;  // the epsilon half of a fused cell
+    const bool flush = flush_eps || hardfail || flush_c;
     if (MODE != MODE_START) {
       if (flush)  // matrix.go:528 / 569
         sink.template token<IS_MATRIX>(tp, p, rl, sentence_end || text_end || !any_tok);
-      if (sent_eps) sink.sentence(p, has_tok);  // matrix.go:575
+      if (sent_eps || sent_c) sink.sentence(p, has_tok);  // matrix.go:575
     }
     any_tok = any_tok || flush;
     has_tok = has_tok || flush;
-    // consume the rune
-    const bool skip = advance && p == tp && nontoken;  // matrix.go:584-588: leading non-token rune
-    p = advance ? p + w : p;
-    rl = skip ? 0u : (advance ? rl + 1u : rl);
-    tp = skip ? p : tp;
-    const bool eot_sent = !sentence_end;  // the EOT fires a SentenceEnd unless one is pending
-    sentence_end = flush ? false : ((sent_eps || eot_now) ? true : sentence_end);
-    text_end = flush ? false : (eot_now ? true : text_end);
+    // consume the rune (for a fused cell: from the epsilon target, right after its rewind, so
+    // the rune is the first of the window)
+    const bool skip = (advance && p == tp && nontoken) || (comp && nontoken);  // matrix.go:584-588
+    const uint32_t p_old = p;
+    p = (advance || comp) ? p + w : p;
+    rl = skip ? 0u : (comp ? 1u : (advance ? rl + 1u : rl));
+    tp = skip ? p : (comp ? p_old : tp);
+    // the EOT fires a SentenceEnd unless one is pending (after the epsilon half of a fused cell)
+    const bool eot_sent = !(flush_c ? false : (sent_c ? true : sentence_end));
+    sentence_end = eot_now ? true : (flush ? false : ((sent_eps || sent_c) ? true : sentence_end));
+    text_end = eot_now ? true : (flush ? false : text_end);
     // retries keep the rune, everything else fetches a new one
     t0 = backtrack ? eps_t : t0; aux0 = backtrack ? eps_aux : aux0;
     p = backtrack ? eps_p : p; rl = backtrack ? eps_rl : rl;
     a = backtrack ? epsilon : (retry_unknown ? unknown : a);
-    newchar = succ || hardfail;
+    newchar = succ || hardfail || comp;
     const bool rewind = flush || (IS_MATRIX && eot_now);  // matrix.go:601 vs datok.go:1019-1030
-    eps_t = (backtrack || rewind) ? 0u : eps_t;
+    eps_t = (backtrack || rewind || comp) ? 0u : eps_t;
+    if (TRANS::FUSED) {
+      // the epsilon target is the state the rune was read in: remembered if it has an epsilon arc
+      const bool he2 = comp && !(IS_MATRIX && eot_now) && tr.has_eps(via, 0u);
+      eps_t = he2 ? via : eps_t; eps_p = he2 ? p_old : eps_p; eps_rl = he2 ? 0u : eps_rl;
+    }
     // rare: EOT calls, the reference's 1024-rune window limit (checked where the window was
     // longest), end of this lane's chunk
-    if (eot_now || (rewind && (hi - bs > DTK_WINDOW || (MODE != MODE_DOC && p >= stop_pos)))) {
+    // a fused cell rewinds before its rune: that rewind is at p_old, never the end of the chunk
+    const bool rewind_end = (flush && !comp) || (IS_MATRIX && eot_now);
+    if (eot_now || (rewind && hi - bs > DTK_WINDOW) || (rewind_end && MODE != MODE_DOC && p >= stop_pos)) {
       if (eot_now) {
         if (MODE != MODE_START) sink.template eot<IS_MATRIX>(p, eot_sent, has_tok);
         has_tok = false;  // TextEnd: pos = pos[:0] (token_writer.go:158)
       }
       if (rewind) {
         if (hi - bs > DTK_WINDOW && count_runes(s, bs, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
-        if (MODE != MODE_DOC && p >= stop_pos) {
+        if (rewind_end && MODE != MODE_DOC && p >= stop_pos) {
           fin.p = p; fin.t = t; fin.aux = aux;
           fin.flags = (sentence_end ? LANE_F_SENT : 0u) | (text_end ? LANE_F_TEXT : 0u) |
                       (ok ? LANE_F_OK : 0u);
@@ -535,9 +594,9 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
         }
       }
     }
-    tp = rewind ? p : tp;  // matrix.go:537-543 / 608-627
-    bs = rewind ? p : bs;
-    rl = rewind ? 0u : rl;
+    tp = rewind_end ? p : tp;  // matrix.go:537-543 / 608-627
+    bs = rewind_end ? p : (flush_c ? p_old : bs);
+    rl = rewind_end ? 0u : rl;
   } while (!done);
 
   if (!stopped && !(st & (ST_STEP_LIMIT | ST_BAD_MODEL))) {
@@ -1202,7 +1261,10 @@ extern "C" int dtk_launch_symbolize(const uint8_t *text, const uint64_t *doc_off
 template <typename F>
 static int with_trans(const DtkTableDev *tab, F &&f) {
   if (tab->kind == DTK_KIND_MATRIX) {
-    if (tab->entry_bytes == 2) {
+    if (tab->fused) {
+      MatrixFusedTrans tr{(const uint32_t *)tab->tab, tab->stride, tab->n_eps, tab->start, tab->ident_guard};
+      f(tr, std::true_type{});
+    } else if (tab->entry_bytes == 2) {
       MatrixTrans<uint16_t> tr{(const uint16_t *)tab->tab, tab->stride, tab->n_eps, tab->start};
       f(tr, std::true_type{});
     } else {

@@ -83,7 +83,7 @@ def test_type_and_loader(gpu, tmp_path):
     assert datok_amd.load_tokenizer_file(str(tmp_path / "junk.matok")) is None
     info = gpu("tokenizer_de.matok").info
     assert (info["epsilon"], info["unknown"], info["identity"]) == (1, 2, 3)
-    assert info["state_count"] == 18400 and info["sigma_count"] == 171 and info["entry_bytes"] == 2
+    assert info["state_count"] == 18400 and info["sigma_count"] == 171 and info["entry_bytes"] in (2, 4)
 
 
 def test_matok_datok_equivalence(gpu):
