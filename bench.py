@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--model", default=MODEL)
     ap.add_argument("--chunk", type=int, default=-1, help="-1 automatic, 0 one lane per document, else bytes")
     ap.add_argument("--warm", type=int, default=48)
+    ap.add_argument("--streams", type=int, default=3,
+                    help="batches in flight: consecutive steps alternate between this many dtk_batch objects "
+                         "(each with its own HIP stream and buffers) over the same resident input")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--parity-docs", type=int, default=256, help="documents checked against the oracle before timing")
@@ -82,10 +85,14 @@ def main():
     t_off = torch.from_numpy(doc_off.view(np.int64)).to(dev)
     torch.cuda.synchronize()
 
-    batch = datok_amd.Batch(total, args.docs)
-    batch.set_chunking(datok_amd.Batch.AUTO_CHUNK if args.chunk < 0 else args.chunk, args.warm)
-    batch.set_input_device(t_text.data_ptr(), t_off.data_ptr(), args.docs, total,
-                           keep=(t_text, t_off), doc_off_host=doc_off)
+    batches = []
+    for _ in range(max(1, args.streams)):
+        bb = datok_amd.Batch(total, args.docs)
+        bb.set_chunking(datok_amd.Batch.AUTO_CHUNK if args.chunk < 0 else args.chunk, args.warm)
+        bb.set_input_device(t_text.data_ptr(), t_off.data_ptr(), args.docs, total,
+                            keep=(t_text, t_off), doc_off_host=doc_off)
+        batches.append(bb)
+    batch = batches[0]
 
     # ---- parity gate (oracle is the checker, never the thing measured)
     batch.run(tok, 0)
@@ -102,9 +109,10 @@ def main():
         del res
 
     # ---- warmup
-    for _ in range(args.warmup):
-        batch.run(tok, 0)
-    batch.sync()
+    for i in range(args.warmup):
+        batches[i % len(batches)].run(tok, 0)
+    for bb in batches:
+        bb.sync()
 
     def barrier():
         if world > 1:
@@ -115,9 +123,10 @@ def main():
     batch.set_profiling(False)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        batch.run(tok, 0)
-    batch.sync()
+    for i in range(args.steps):
+        batches[i % len(batches)].run(tok, 0)
+    for bb in batches:
+        bb.sync()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
@@ -126,16 +135,23 @@ def main():
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
 
-    # ---- per-kernel time of the dominant kernel (the walk), HIP events on the
-    #      batch's own stream, same K steps again (events add no host sync)
-    batch.set_profiling(True)
-    stage_sum = {}
-    for _ in range(args.steps):
-        batch.run(tok, 0)
-        for k, v in batch.stage_ms().items():
-            stage_sum[k] = stage_sum.get(k, 0.0) + v
-    stage_avg = {k: v / args.steps for k, v in stage_sum.items()}
-    batch.set_profiling(False)
+    # ---- per-kernel time of the dominant kernel (the walk): HIP events on each batch's own
+    #      stream, in the same regime as the timed region (same number of batches in flight,
+    #      no host synchronisation between steps); the events of the last run of every batch
+    #      are read after the region, and the region is repeated a few times
+    for bb in batches:
+        bb.set_profiling(True)
+    stage_sum, n_samples = {}, 0
+    for rep in range(4):
+        for i in range(max(args.steps // 4, 2 * len(batches))):
+            batches[i % len(batches)].run(tok, 0)
+        for bb in batches:
+            for k, v in bb.stage_ms().items():
+                stage_sum[k] = stage_sum.get(k, 0.0) + v
+            n_samples += 1
+    stage_avg = {k: v / n_samples for k, v in stage_sum.items()}
+    for bb in batches:
+        bb.set_profiling(False)
 
     # ---- offset gather to rank 0 over RCCL (config 5's exchange), outside the clock
     gather_ms = None
@@ -217,7 +233,8 @@ def main():
             "config": {"workload": "tokenizer_de.matok, %d equal-length %d B synthetic German docs per GPU "
                                    "(BASELINE.json configs[1])" % (args.docs, args.doc_bytes),
                        "docs_per_gpu": args.docs, "doc_bytes": args.doc_bytes,
-                       "parallelism": "documents sharded over %d GPU(s), no data-path collective" % world},
+                       "parallelism": "documents sharded over %d GPU(s), no data-path collective" % world,
+                       "batches_in_flight": len(batches)},
             "roofline": {"bound": "hbm",
                          "kernel": "k_spec_walk<MatrixTrans<u16>>" if tot["chunk_bytes"] else "k_walk_doc<MatrixTrans<u16>>",
                          "achieved": round(achieved, 2),

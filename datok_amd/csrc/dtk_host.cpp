@@ -642,10 +642,12 @@ static int plan_lanes(dtk_batch *b) {
   if (C == 0xFFFFFFFFu) {
     // enough lanes to give every SIMD of the chip a few waves, but chunks no shorter than
     // a few warm-ups: 256 CUs x 4 SIMDs x 64 lanes = 65536 lanes per "wave per SIMD"
-    const uint64_t want_lanes = 2ull * 65536ull;  // measured best on 16 MiB: C = 128
+    // measured: 128 is best for 16 MiB (131072 lanes = 2 waves per SIMD); large batches are
+    // flat from 128 to 1024 and lose beyond (fewer lanes than the chip holds)
+    const uint64_t want_lanes = 4ull * 65536ull;
     uint64_t c = b->total / want_lanes;
     uint32_t p2 = 128;
-    while (p2 < c && p2 < 4096) p2 <<= 1;
+    while (p2 * 2 <= c && p2 < 1024) p2 <<= 1;
     C = p2;
   }
   b->chunk = C;
