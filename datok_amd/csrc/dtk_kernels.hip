@@ -566,6 +566,7 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
     t0 = backtrack ? eps_t : t0; aux0 = backtrack ? eps_aux : aux0;
     p = backtrack ? eps_p : p; rl = backtrack ? eps_rl : rl;
     a = backtrack ? epsilon : (retry_unknown ? unknown : a);
+    eot = retry_unknown ? false : eot;  // matrix.go:555: a retry forgets that the rune was EOT
     newchar = succ || hardfail || comp;
     const bool rewind = flush || (IS_MATRIX && eot_now);  // matrix.go:601 vs datok.go:1019-1030
     eps_t = (backtrack || rewind || comp) ? 0u : eps_t;

@@ -146,6 +146,7 @@ def _edge_docs():
             "This.\n\x04And.\n\x04\n".encode(), "\nThis.\n\x04\nAnd.\n\x04\n".encode(),
             "Tree\n\x04\n".encode(), "Erste.\n\n\n\n\x04\nNächst.\x04".encode(),
             "word\x04 more words. And\x04more".encode(), "a\x04b\x04c".encode(),
+            "x\x04y \x04 z\x04".encode(), "ibauamt\x04dead. \x04".encode(),
             "„Zitat“ – so … ‚x‘ »y« ∞ ≠ ≤ 日本語 テスト".encode(), "😀 emoji 👍🏽 ok".encode(),
             b"\xff\xfe invalid \x80\x80 bytes \xc3", b"\xe2\x82", b"\xf0\x9f\x98", b"ab\xc0\xafcd",
             b"x" * 1100, b" " * 1100 + b"x", b"a " * 700, ("ä" * 1030).encode(), b"." * 300,
