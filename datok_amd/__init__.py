@@ -13,9 +13,12 @@ HIP kernels behind the C-ABI of libdatok_gpu.so (include/datok_gpu.h):
     tok.Transduce(r, w) bool             Tokenizer.transduce(r, w)            (matrix.go:340-342)
     tok.TransduceTokenWriter(r, tw) bool Tokenizer.transduce_token_writer(r, tw) (matrix.go:348-698)
     tok.Type() string                    Tokenizer.type()                     (matrix.go:102)
+    LoadFomaFile(f).ToMatrix()           load_foma_file(f)                    (fomafile.go:56-450, matrix.go:30-99)
+    `datok convert` (matrix)             foma_to_matok(bytes) -> bytes        (cmd/datok.go:50-70)
     --                                   Batch: many documents per launch (addition)
 """
 from ._lib import (DatokGpuError, ST_BAD_MODEL, ST_EMPTY_TEXT, ST_IRREGULAR, ST_STEP_LIMIT,  # noqa: F401
                    ST_WINDOW_OVERFLOW, build, lib)
 from .host import (NEWLINE_AFTER_EOT, SENTENCE_POS, SENTENCES, SIMPLE, TOKEN_POS, TOKENS, Batch,  # noqa: F401
-                   BatchResult, TokenWriter, Tokenizer, load_tokenizer_file, new_token_writer, replay)
+                   BatchResult, TokenWriter, Tokenizer, foma_to_matok, load_foma_file, load_tokenizer_file,
+                   new_token_writer, replay)

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DATOK_GPU_LIB") or os.path.join(_HERE, "libdatok_gpu.so")
 
 # error codes / flags (datok_gpu.h)
-OK, E_IO, E_FORMAT, E_NO_DEVICE, E_HIP, E_ARG, E_MODEL, E_CAPACITY, E_STATE = 0, -1, -2, -3, -4, -5, -6, -7, -8
+OK, E_IO, E_FORMAT, E_NO_DEVICE, E_HIP, E_ARG, E_MODEL, E_CAPACITY, E_STATE, E_NOMEM = 0, -1, -2, -3, -4, -5, -6, -7, -8, -9
 ST_WINDOW_OVERFLOW, ST_EMPTY_TEXT, ST_BAD_MODEL, ST_IRREGULAR, ST_STEP_LIMIT, ST_INTERNAL = 1, 2, 4, 8, 16, 32
 
 EXPORTS = [
@@ -22,6 +22,7 @@ EXPORTS = [
     "dtk_batch_run", "dtk_batch_sync", "dtk_batch_stream", "dtk_batch_totals",
     "dtk_batch_set_profiling", "dtk_batch_stage_ms", "dtk_batch_set_chunking",
     "dtk_batch_result_device", "dtk_batch_result_host", "dtk_transduce", "dtk_free",
+    "dtk_foma_to_matok",
 ]
 
 
@@ -112,6 +113,8 @@ def lib():
     L.dtk_batch_result_device.argtypes = [vp, C.POINTER(ResultView)]
     L.dtk_batch_result_host.argtypes = [vp, C.POINTER(ResultView)]
     L.dtk_transduce.argtypes = [vp, C.c_char_p, sz, u32, C.POINTER(vp), C.POINTER(sz), C.POINTER(u32)]
+    L.dtk_foma_to_matok.argtypes = [vp, C.c_size_t, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.dtk_foma_to_matok.restype = C.c_int
     L.dtk_free.argtypes = [vp]
     L.dtk_free.restype = None
     _lib = L

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <string_view>
 #include <vector>
 
 #include "../../include/datok_gpu.h"
@@ -41,6 +42,7 @@ extern "C" const char *dtk_strerror(int code) {
     case DTK_E_MODEL: return "model outside device limits (symbols >= 2048, special ids out of range, epsilon cycle)";
     case DTK_E_CAPACITY: return "batch exceeds the capacity it was created with";
     case DTK_E_STATE: return "call out of order";
+    case DTK_E_NOMEM: return "out of host memory";
     default: return "unknown error";
   }
 }
@@ -176,7 +178,9 @@ static int upload(dtk_model *m, const void *tab, size_t tab_bytes) {
   m->sig.runes = m->d_runes;
   m->sig.syms = m->d_syms;
   m->sig.n_runes = (uint32_t)nr;
-  m->sig.identity = (uint32_t)m->identity;
+  // a net without identity symbol (-1, fomafile.go:88): unmapped runes get symbol 0, which has
+  // no arcs (matrix.go:459), and no symbol ever equals the identity (matrix.go:478)
+  m->sig.identity = m->identity < 0 ? 0u : (uint32_t)m->identity;
   m->tab.tab = m->d_tab;
   m->tab.epsilon = (uint32_t)m->epsilon;
   m->tab.unknown = (uint32_t)m->unknown;
@@ -189,10 +193,12 @@ static bool special_ids_ok(const dtk_model *m) {
   // identity == unknown makes the retry of matrix.go:478-485 spin forever upstream.
   return m->sigma_count >= 1 && m->sigma_count <= (int)DTK_SYM_MAX && m->epsilon >= 1 &&
          m->epsilon < m->sigma_count && m->unknown < m->sigma_count && m->identity < m->sigma_count &&
-         m->identity != m->unknown && m->epsilon != m->identity;
+         (m->identity != m->unknown || m->identity < 0) && m->epsilon != m->identity;
 }
 
-// ParseMatrix (matrix.go:235-337) + device layout.
+static int layout_matrix(dtk_model *m, const std::vector<uint32_t> &arr);
+
+// ParseMatrix (matrix.go:235-337)
 static int build_matrix(dtk_model *m, const std::vector<uint8_t> &raw) {
   if (raw.size() < 19) return DTK_E_FORMAT;
   const uint8_t *h = raw.data() + 5;
@@ -209,11 +215,17 @@ static int build_matrix(dtk_model *m, const std::vector<uint8_t> &raw) {
   off++;
   if (raw.size() - off < m->array_len * 4) return DTK_E_FORMAT;   // matrix.go:327-330
   if (!special_ids_ok(m) || m->state_count == 0 || m->state_count >= 0x7FFFFFFFu) return DTK_E_MODEL;
+  std::vector<uint32_t> arr(m->array_len);
+  for (uint64_t x = 0; x < m->array_len; x++) arr[x] = rd32(raw.data() + off + x * 4);
+  return layout_matrix(m, arr);
+}
 
+// Device layout of a matrix tokenizer whose header fields and sigma are set in `m` and whose
+// symbol-major array (matrix.go:463) is `arr`.
+static int layout_matrix(dtk_model *m, const std::vector<uint32_t> &arr) {
   const uint64_t N = m->state_count, S = (uint64_t)m->sigma_count;
-  const uint8_t *cells = raw.data() + off;
   auto cell = [&](uint64_t a, uint64_t t) -> uint32_t {  // array[(a-1)*stateCount + t], matrix.go:463
-    return rd32(cells + ((a - 1) * N + t) * 4);
+    return arr[(a - 1) * N + t];
   };
 
   // renumber: states with an epsilon arc first (probe of matrix.go:442 -> compare)
@@ -367,6 +379,246 @@ static int build_datok(dtk_model *m, const std::vector<uint8_t> &raw) {
   return upload(m, dev.data(), dev.size() * 4);
 }
 
+// ------------------------------------------------------------- foma text nets
+//
+// LoadFomaFile/ParseFoma (fomafile.go:56-450) followed by Automaton.ToMatrix (matrix.go:30-99):
+// a deterministic, epsilon-free Foma net in text form becomes the matrix tokenizer.  The
+// double-array construction (ToDoubleArray, datok.go:95-250) is an offline step and not built.
+namespace {
+struct FomaArc { int32_t end; bool nontoken; };
+struct FomaNet {
+  int epsilon = -1, unknown = -1, identity = -1, final_sym = -1, tokenend = -1;
+  int sigma_count = 0, state_count = -1;
+  std::vector<std::pair<int, uint32_t>> chars;  // (symbol number, rune) -- sigmaRev
+  std::vector<char> mcs;                        // symbol number -> multi-character symbol
+  std::vector<std::vector<std::pair<int, FomaArc>>> arcs;  // per state (1-based): last write wins
+};
+
+static std::vector<std::string_view> split_sp(std::string_view s, size_t max_parts) {
+  std::vector<std::string_view> out;
+  while (out.size() + 1 < max_parts) {
+    const size_t k = s.find(' ');
+    if (k == std::string_view::npos) break;
+    out.push_back(s.substr(0, k));
+    s.remove_prefix(k + 1);
+  }
+  out.push_back(s);
+  return out;
+}
+
+static bool to_int(std::string_view s, int &v) {  // strconv.Atoi
+  if (s.empty()) return false;
+  size_t i = (s[0] == '-' || s[0] == '+') ? 1 : 0;
+  if (i == s.size()) return false;
+  long long x = 0;
+  for (; i < s.size(); i++) {
+    if (s[i] < '0' || s[i] > '9') return false;
+    x = x * 10 + (s[i] - '0');
+    if (x > 0x7FFFFFFFll) return false;
+  }
+  v = (int)(s[0] == '-' ? -x : x);
+  return true;
+}
+
+static int parse_foma(const std::vector<uint8_t> &raw, FomaNet &net) {
+  enum { NONE, PROPS, SIGMA, STATES } mode = NONE;
+  std::string_view rest((const char *)raw.data(), raw.size());
+  int state = 0, in_sym = 0, out_sym = 0, end = 0, fin = 0;
+  auto next_line = [&](std::string_view &line) -> bool {  // ReadString('\n'), fomafile.go:101-108
+    const size_t k = rest.find('\n');
+    if (k == std::string_view::npos) return false;  // an unterminated last line is dropped
+    line = rest.substr(0, k);                       // without the newline
+    rest.remove_prefix(k + 1);
+    return true;
+  };
+  auto set_arc = [&](int st, int sym, FomaArc a) {
+    auto &v = net.arcs[(size_t)st];
+    for (auto &e : v) if (e.first == sym) { e.second = a; return; }
+    v.emplace_back(sym, a);
+  };
+  std::string_view line;
+  while (next_line(line)) {
+    if (line.substr(0, 2) == "##") {  // fomafile.go:111-135
+      if (line.substr(0, 9) == "##props##") mode = PROPS;
+      else if (line.substr(0, 10) == "##states##") { mode = STATES; net.final_sym = ++net.sigma_count; }
+      else if (line.substr(0, 9) == "##sigma##") mode = SIGMA;
+      else if (line.substr(0, 7) == "##end##") mode = NONE;
+      else if (line.substr(0, 10) != "##foma-net") break;
+      continue;
+    }
+    if (mode == PROPS) {  // fomafile.go:140-187
+      auto f = split_sp(line, 64);
+      if (f.size() < 10 || f[6] != "1" || f[9] != "1") return DTK_E_MODEL;  // deterministic, epsilon free
+      int arcs_n;
+      if (!to_int(f[1], arcs_n) || !to_int(f[2], net.state_count) || net.state_count < 1) return DTK_E_FORMAT;
+      net.arcs.assign((size_t)net.state_count + 2, {});
+    } else if (mode == SIGMA) {  // fomafile.go:372-444
+      auto f = split_sp(line, 2);
+      int number;
+      if (f.size() < 2 || !to_int(f[0], number) || number < 0 || number > 0xFFFF) return DTK_E_FORMAT;
+      number++;
+      net.sigma_count = number;
+      if ((size_t)number >= net.mcs.size()) net.mcs.resize((size_t)number + 1, 0);
+      const std::string_view sym = f[1];
+      size_t runes = 0;
+      uint32_t r = 0;
+      for (size_t i = 0; i < sym.size(); runes++)
+        i += (size_t)go_decode_host((const uint8_t *)sym.data() + i, sym.size() - i, &r);
+      if (runes == 1) {
+        net.chars.emplace_back(number, r);
+      } else if (runes > 1) {
+        if (sym == "@_EPSILON_SYMBOL_@") net.epsilon = number;
+        else if (sym == "@_UNKNOWN_SYMBOL_@") net.unknown = number;
+        else if (sym == "@_IDENTITY_SYMBOL_@") net.identity = number;
+        else if (sym == "@_TOKEN_SYMBOL_@" || sym == "@_TOKEN_BOUND_@") net.tokenend = number;
+        else net.mcs[(size_t)number] = 1;
+      } else {  // the newline symbol spans two lines (fomafile.go:423-436)
+        std::string_view more;
+        if (!next_line(more)) return DTK_E_FORMAT;
+        if (more.empty()) net.chars.emplace_back(number, (uint32_t)'\n');
+        else net.mcs[(size_t)number] = 1;
+      }
+    } else if (mode == STATES) {  // fomafile.go:189-369
+      if (net.state_count < 0) return DTK_E_FORMAT;
+      auto f = split_sp(line, 64);
+      if (f[0] == "-1") continue;
+      int e[5] = {0, 0, 0, 0, 0};
+      const size_t nf = f.size();
+      for (size_t i = 0; i < nf && i < 5; i++)
+        if (!to_int(f[i], e[i])) return DTK_E_FORMAT;
+      if (nf == 5) { state = e[0]; in_sym = e[1]; out_sym = e[2]; end = e[3]; fin = e[4]; }
+      else if (nf == 4) {
+        if (e[1] == -1) {  // final state without outgoing arcs
+          state = e[0]; fin = e[3];
+          if (state < 0 || state + 1 > net.state_count) return DTK_E_MODEL;
+          if (fin == 1) set_arc(state + 1, net.final_sym, FomaArc{0, false});
+          continue;
+        }
+        state = e[0]; in_sym = out_sym = e[1]; end = e[2]; fin = e[3];
+      } else if (nf == 3) { in_sym = e[0]; out_sym = e[1]; end = e[2]; }
+      else if (nf == 2) { in_sym = out_sym = e[0]; end = e[1]; }
+      const int is = in_sym + 1, os = out_sym + 1;
+      bool nontoken = false;
+      if (is != os) {
+        if (os == net.tokenend && is == net.epsilon) { /* token boundary, kept under epsilon */ }
+        else if (os == net.epsilon) nontoken = true;
+        else return DTK_E_MODEL;  // unsupported transition
+      } else if (is == net.tokenend) continue;
+      else if (is == net.epsilon) return DTK_E_MODEL;  // general epsilon transitions
+      else if (is >= 0 && (size_t)is < net.mcs.size() && net.mcs[(size_t)is]) continue;
+      if (state < 0 || state + 1 > net.state_count || end < -1 || end + 1 > net.state_count) return DTK_E_MODEL;
+      if (is >= 0) set_arc(state + 1, is, FomaArc{end + 1, nontoken});
+      if (fin == 1) set_arc(state + 1, net.final_sym, FomaArc{0, false});
+    }
+  }
+  if (net.state_count < 1 || net.epsilon < 1) return DTK_E_FORMAT;
+  return DTK_OK;
+}
+
+// Automaton.ToMatrix, matrix.go:30-99: header fields and sigma into `m`, the array into `arr`
+static int foma_to_matrix(dtk_model *m, const std::vector<uint8_t> &raw, std::vector<uint32_t> &arr) {
+  FomaNet net;
+  int rc = parse_foma(raw, net);
+  if (rc != DTK_OK) return rc;
+  int max = net.identity != -1 ? net.identity : 0;
+  for (auto &c : net.chars) max = std::max(max, c.first);
+  m->kind = DTK_KIND_MATRIX;
+  m->epsilon = net.epsilon; m->unknown = net.unknown; m->identity = net.identity;
+  m->state_count = (uint32_t)net.state_count;
+  m->sigma_count = max + 1;
+  m->array_len = ((uint64_t)m->state_count + 1) * (uint64_t)m->sigma_count;
+  if (!special_ids_ok(m)) return DTK_E_MODEL;
+  for (int i = 0; i < 256; i++) m->ascii[i] = net.identity != -1 ? (uint16_t)net.identity : 0;  // :43-48
+  std::vector<std::pair<uint32_t, uint16_t>> ent;
+  for (auto &c : net.chars) {
+    if (c.second < 256) m->ascii[c.second] = (uint16_t)c.first;
+    ent.emplace_back(c.second, (uint16_t)c.first);
+  }
+  std::stable_sort(ent.begin(), ent.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+  for (auto &e : ent) {
+    if (!m->sigma_runes.empty() && m->sigma_runes.back() == e.first) m->sigma_syms.back() = e.second;
+    else { m->sigma_runes.push_back(e.first); m->sigma_syms.push_back(e.second); }
+  }
+  // only what is reachable from state 1 enters the matrix (matrix.go:76-96)
+  const uint64_t N = m->state_count;
+  arr.assign(m->array_len, 0);
+  std::vector<char> seen(N + 2, 0);
+  std::vector<uint32_t> todo{1};
+  seen[1] = 1;
+  while (!todo.empty()) {
+    const uint32_t st = todo.back();
+    todo.pop_back();
+    for (auto &e : net.arcs[st]) {
+      const uint64_t at = (uint64_t)(e.first - 1) * N + st;
+      if (e.first >= 1 && at < arr.size())
+        arr[at] = (uint32_t)e.second.end | (e.second.nontoken ? DTK_FIRSTBIT : 0u);
+      const int32_t to = e.second.end;
+      if (to >= 1 && (uint64_t)to <= N && !seen[(size_t)to]) { seen[(size_t)to] = 1; todo.push_back((uint32_t)to); }
+    }
+  }
+  return DTK_OK;
+}
+
+static int build_foma(dtk_model *m, const std::vector<uint8_t> &raw) {
+  std::vector<uint32_t> arr;
+  int rc = foma_to_matrix(m, raw, arr);
+  return rc != DTK_OK ? rc : layout_matrix(m, arr);
+}
+
+static void put_rune(std::vector<uint8_t> &o, uint32_t r) {  // bufio.Writer.WriteRune
+  if (r > 0x10FFFF || (r >= 0xD800 && r <= 0xDFFF)) r = 0xFFFD;
+  if (r < 0x80) o.push_back((uint8_t)r);
+  else if (r < 0x800) { o.push_back(0xC0 | (r >> 6)); o.push_back(0x80 | (r & 0x3F)); }
+  else if (r < 0x10000) { o.push_back(0xE0 | (r >> 12)); o.push_back(0x80 | ((r >> 6) & 0x3F)); o.push_back(0x80 | (r & 0x3F)); }
+  else { o.push_back(0xF0 | (r >> 18)); o.push_back(0x80 | ((r >> 12) & 0x3F)); o.push_back(0x80 | ((r >> 6) & 0x3F)); o.push_back(0x80 | (r & 0x3F)); }
+}
+}  // namespace
+
+// `datok convert -f foma -t file` without --double-array (cmd/datok.go:50-70): LoadFomaFile,
+// ToMatrix, then MatrixTokenizer.Save/WriteTo (matrix.go:107-210) into a gzip image.  Host only.
+extern "C" int dtk_foma_to_matok(const void *gz_bytes, size_t n, void **out, size_t *out_n) {
+  if (!gz_bytes || !out || !out_n) return DTK_E_ARG;
+  *out = nullptr; *out_n = 0;
+  std::vector<uint8_t> raw;
+  int rc = gunzip((const uint8_t *)gz_bytes, n, raw);
+  if (rc != DTK_OK) return rc;
+  if (raw.size() < 10 || memcmp(raw.data(), "##foma-net", 10) != 0) return DTK_E_FORMAT;
+  dtk_model m;
+  std::vector<uint32_t> arr;
+  rc = foma_to_matrix(&m, raw, arr);
+  if (rc != DTK_OK) return rc;
+  // WriteTo: the sigma list ends at the largest character symbol (matrix.go:138-153)
+  uint32_t max = 0;
+  for (auto s : m.sigma_syms) max = std::max<uint32_t>(max, s);
+  std::vector<uint32_t> list(max + 1, 0);
+  for (size_t i = 0; i < m.sigma_runes.size(); i++) list[m.sigma_syms[i]] = m.sigma_runes[i];
+  std::vector<uint8_t> img;
+  auto p16 = [&](uint32_t v) { img.push_back((uint8_t)v); img.push_back((uint8_t)(v >> 8)); };
+  auto p32 = [&](uint32_t v) { p16(v & 0xFFFF); p16(v >> 16); };
+  img.insert(img.end(), {'M', 'A', 'T', 'O', 'K'});
+  p16(1); p16((uint32_t)m.epsilon); p16((uint32_t)m.unknown); p16((uint32_t)m.identity);
+  p32(m.state_count); p16(max + 1);
+  for (uint32_t r : list) put_rune(img, r);
+  img.push_back('M');
+  for (uint32_t x : arr) p32(x);
+  // gzip.NewWriter(f)
+  z_stream zs;
+  memset(&zs, 0, sizeof zs);
+  if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 16 + MAX_WBITS, 8, Z_DEFAULT_STRATEGY) != Z_OK)
+    return DTK_E_NOMEM;
+  const uLong bound = deflateBound(&zs, (uLong)img.size());
+  uint8_t *buf = (uint8_t *)malloc(bound);
+  if (!buf) { deflateEnd(&zs); return DTK_E_NOMEM; }
+  zs.next_in = img.data(); zs.avail_in = (uInt)img.size();
+  zs.next_out = buf; zs.avail_out = (uInt)bound;
+  rc = deflate(&zs, Z_FINISH);
+  const size_t have = bound - zs.avail_out;
+  deflateEnd(&zs);
+  if (rc != Z_STREAM_END) { free(buf); return DTK_E_NOMEM; }
+  *out = buf; *out_n = have;
+  return DTK_OK;
+}
+
 extern "C" int dtk_model_load_mem(const void *gz_bytes, size_t n, dtk_model **out) {
   if (!gz_bytes || !out) return DTK_E_ARG;
   *out = nullptr;
@@ -378,6 +630,7 @@ extern "C" int dtk_model_load_mem(const void *gz_bytes, size_t n, dtk_model **ou
   dtk_model *m = new dtk_model();
   if (memcmp(raw.data(), "MATOK", 5) == 0) rc = build_matrix(m, raw);      // fomafile.go:476
   else if (memcmp(raw.data(), "DATOK", 5) == 0) rc = build_datok(m, raw);  // fomafile.go:478
+  else if (raw.size() >= 10 && memcmp(raw.data(), "##foma-net", 10) == 0) rc = build_foma(m, raw);
   else rc = DTK_E_FORMAT;                                                  // fomafile.go:482
   if (rc != DTK_OK) { dtk_model_free(m); return rc; }
   *out = m;

@@ -353,3 +353,21 @@ class Batch:
         r.events = arr(v.events, n_ev, np.uint8) | arr(v.events_open, n_ev, np.uint8)
         r.doc_off = self._doc_off
         return r
+
+
+def foma_to_matok(foma_gz: bytes) -> bytes:
+    """`datok convert` (cmd/datok.go:50-70, matrix variant): LoadFomaFile + ToMatrix + Save.
+
+    Takes the bytes of a gzip'd Foma text net and returns the bytes of the .matok file. Host only.
+    """
+    out, n = C.c_void_p(), C.c_size_t()
+    check(lib().dtk_foma_to_matok(foma_gz, len(foma_gz), C.byref(out), C.byref(n)), "foma_to_matok")
+    try:
+        return C.string_at(out, n.value)
+    finally:
+        lib().dtk_free(out)
+
+
+def load_foma_file(path):
+    """LoadFomaFile(path).ToMatrix() (fomafile.go:56-75, matrix.go:30-99) on the device."""
+    return load_tokenizer_file(path)

@@ -33,9 +33,11 @@ enum {
   DTK_E_NO_DEVICE = -3, /* no usable HIP device */
   DTK_E_HIP = -4,       /* a HIP runtime call failed; dtk_last_hip_error() has the text */
   DTK_E_ARG = -5,       /* invalid argument */
-  DTK_E_MODEL = -6,     /* model outside device limits (>= 2048 symbols, epsilon cycle, ids out of range) */
+  DTK_E_MODEL = -6,     /* model outside device limits (>= 2048 symbols, epsilon cycle, ids out of range),
+                           or a Foma net ParseFoma rejects (fomafile.go:159-167,283-310) */
   DTK_E_CAPACITY = -7,  /* batch larger than the dtk_batch was created for */
-  DTK_E_STATE = -8      /* call order (e.g. result requested before a run) */
+  DTK_E_STATE = -8,     /* call order (e.g. result requested before a run) */
+  DTK_E_NOMEM = -9      /* host allocation failed */
 };
 
 /* ---- Bits, token_writer.go:17-25 (same values) ---- */
@@ -78,6 +80,12 @@ const char *dtk_last_hip_error(void);
 int dtk_model_load(const char *path, dtk_model **out);
 int dtk_model_load_mem(const void *gz_bytes, size_t n, dtk_model **out); /* ParseMatrix/ParseDatok on a gzip blob */
 void dtk_model_free(dtk_model *m);
+/* Both loaders also accept a gzip'd Foma text net ("##foma-net ..."): LoadFomaFile + Automaton.ToMatrix
+ * (fomafile.go:56-450, matrix.go:30-99), i.e. what the reference's tests build their tiny tokenizers with.
+ * dtk_foma_to_matok is `datok convert` without --double-array (cmd/datok.go:50-70): the same conversion
+ * followed by MatrixTokenizer.Save (matrix.go:107-210) into a gzip image (*out, free with dtk_free).
+ * Host only: needs no device.  ToDoubleArray (datok.go:95-250) is not provided. */
+int dtk_foma_to_matok(const void *gz_bytes, size_t n, void **out, size_t *out_n);
 const char *dtk_model_type(const dtk_model *m); /* Tokenizer.Type(): "MATOK" / "DATOK" (matrix.go:102, datok.go:252) */
 
 typedef struct {

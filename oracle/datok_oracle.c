@@ -525,7 +525,7 @@ static int walk_matrix(const orc_model *m, const uint8_t *in, size_t n, const si
           a = m->sigma_ascii[ch];
         } else { /* :427-435; `ok` keeps its value between these visits */
           a = orc_sigma_lookup(m, ch, &ok);
-          if (!ok) a = identity;
+          if (!ok && identity != -1) a = identity; /* a map miss leaves a == 0 */
         }
         t0 = t; /* :437 */
         {
@@ -705,7 +705,7 @@ static int walk_da(const orc_model *m, const uint8_t *in, size_t n, const sink *
           a = m->sigma_ascii[ch];
         } else { /* :865-870 */
           a = orc_sigma_lookup(m, ch, &ok);
-          if (!ok) a = identity;
+          if (!ok && identity != -1) a = identity; /* a map miss leaves a == 0 */
         }
         t0 = t; /* :873 */
         if (t0 >= alen) { *status |= ORC_ST_BAD_MODEL; ret = 0; goto done; }
@@ -943,3 +943,201 @@ void orc_count_batch(const orc_model *m, const uint8_t *text, const uint64_t *do
 }
 
 void orc_free(void *p) { free(p); }
+
+/* ------------------------------------------------------------ foma -> matrix */
+
+/* fomafile.go:77-450 ParseFoma + matrix.go:30-99 Automaton.ToMatrix, restated: a Foma
+ * text net becomes the matrix tokenizer `foma.ToMatrix()` would build.  Used for the
+ * reference's tiny-FST tests (matrix_test.go:25-105,182-206, datok_test.go:57-230). */
+typedef struct { int in_sym, end, nontoken, used; } fedge;
+
+static int str_runecount(const char *s, size_t n) {
+  int k = 0; size_t i = 0; uint32_t r;
+  while (i < n) { i += (size_t)orc_decode_rune((const uint8_t *)s + i, n - i, &r); k++; }
+  return k;
+}
+
+orc_model *orc_parse_foma(const uint8_t *raw, size_t n) {
+  int eps = -1, unk = -1, idt = -1, fin = -1, tokend = -1, sigma_count = 0, state_count = -1;
+  uint32_t *sig_rune = NULL; char *sig_is_mcs = NULL; int sig_cap = 0;
+  /* transitions[state][sym] as a dense table grown on demand */
+  fedge *tr = NULL; int tr_syms = 0;
+  int mode = 0, state = 0, in_sym = 0, out_sym = 0, end = 0, final = 0;
+  size_t pos = 0;
+  orc_model *m = NULL;
+#define SIG_ENSURE(k) do { if ((k) >= sig_cap) { int nc = (k) + 64; \
+    sig_rune = (uint32_t *)realloc(sig_rune, sizeof(uint32_t) * (size_t)nc); \
+    sig_is_mcs = (char *)realloc(sig_is_mcs, (size_t)nc); \
+    for (int q = sig_cap; q < nc; q++) { sig_rune[q] = 0; sig_is_mcs[q] = 0; } sig_cap = nc; } } while (0)
+  while (pos < n) {
+    /* r.ReadString('\n'): a last line without newline is dropped (fomafile.go:101-108) */
+    const uint8_t *nl = (const uint8_t *)memchr(raw + pos, '\n', n - pos);
+    if (!nl) break;
+    const char *line = (const char *)raw + pos;
+    size_t len = (size_t)(nl - (raw + pos)) + 1; /* includes '\n' */
+    pos += len;
+    if (len >= 2 && line[0] == '#' && line[1] == '#') { /* :111-135 */
+      if (!strncmp(line, "##props##", 9)) mode = 1;
+      else if (!strncmp(line, "##states##", 10)) { mode = 3; sigma_count++; fin = sigma_count; }
+      else if (!strncmp(line, "##sigma##", 9)) mode = 2;
+      else if (!strncmp(line, "##end##", 7)) mode = 4;
+      else if (strncmp(line, "##foma-net", 10)) break;
+      continue;
+    }
+    if (mode == 1) { /* props :140-187 */
+      int f[13]; int nf = 0; const char *p = line;
+      char fields[13][32];
+      while (nf < 13) {
+        const char *sp = (const char *)memchr(p, ' ', (size_t)(line + len - p));
+        size_t l = sp ? (size_t)(sp - p) : (size_t)(line + len - p);
+        if (l > 31) l = 31;
+        memcpy(fields[nf], p, l); fields[nf][l] = 0; nf++;
+        if (!sp) break;
+        p = sp + 1;
+      }
+      (void)f;
+      if (nf < 10 || strcmp(fields[6], "1") || strcmp(fields[9], "1")) goto fail; /* deterministic, eps free */
+      state_count = atoi(fields[2]);
+      continue;
+    }
+    if (mode == 2) { /* sigma :372-444 */
+      const char *body = line; size_t bl = len - 1; /* line[0:len-1] */
+      const char *sp = (const char *)memchr(body, ' ', bl);
+      if (!sp) goto fail;
+      int number = atoi(body) + 1;
+      sigma_count = number;
+      const char *sym = sp + 1; size_t sl = bl - (size_t)(sym - body);
+      int rc = str_runecount(sym, sl);
+      uint32_t symbol;
+      SIG_ENSURE(number);
+      if (rc == 1) {
+        orc_decode_rune((const uint8_t *)sym, sl, &symbol);
+      } else if (rc > 1) {
+        if (sl == 18 && !memcmp(sym, "@_EPSILON_SYMBOL_@", 18)) eps = number;
+        else if (sl == 18 && !memcmp(sym, "@_UNKNOWN_SYMBOL_@", 18)) unk = number;
+        else if (sl == 19 && !memcmp(sym, "@_IDENTITY_SYMBOL_@", 19)) idt = number;
+        else if (sl == 16 && !memcmp(sym, "@_TOKEN_SYMBOL_@", 16)) tokend = number;
+        else if (sl == 15 && !memcmp(sym, "@_TOKEN_BOUND_@", 15)) tokend = number;
+        else sig_is_mcs[number] = 1;
+        continue;
+      } else { /* probably the newline symbol: its second half is the next line */
+        const uint8_t *nl2 = pos < n ? (const uint8_t *)memchr(raw + pos, '\n', n - pos) : NULL;
+        if (!nl2) goto fail;
+        size_t l2 = (size_t)(nl2 - (raw + pos)) + 1;
+        pos += l2;
+        if (l2 != 1) { sig_is_mcs[number] = 1; continue; }
+        symbol = '\n';
+      }
+      sig_rune[number] = symbol;
+      continue;
+    }
+    if (mode == 3) { /* states :189-369 */
+      int e[5], ne = 0; const char *p = line; const char *lim = line + len - 1;
+      if (state_count < 0) goto fail;
+      while (ne < 5 && p <= lim) {
+        const char *sp = (const char *)memchr(p, ' ', (size_t)(lim - p));
+        e[ne++] = atoi(p);
+        if (!sp) break;
+        p = sp + 1;
+      }
+      if (ne == 0 || e[0] == -1) continue;
+      if (!tr) {
+        tr_syms = sigma_count + 2;
+        tr = (fedge *)calloc((size_t)(state_count + 2) * (size_t)tr_syms, sizeof(fedge));
+      }
+#define TR(s, a) tr[(size_t)(s) * (size_t)tr_syms + (size_t)(a)]
+      if (ne == 5) { state = e[0]; in_sym = e[1]; out_sym = e[2]; end = e[3]; final = e[4]; }
+      else if (ne == 4) {
+        if (e[1] == -1) { /* final state without outgoing edges */
+          state = e[0]; final = e[3];
+          if (final == 1 && state + 1 <= state_count) { TR(state + 1, fin).used = 1; TR(state + 1, fin).end = 0; }
+          continue;
+        }
+        state = e[0]; in_sym = e[1]; end = e[2]; final = e[3]; out_sym = in_sym;
+      } else if (ne == 3) { in_sym = e[0]; out_sym = e[1]; end = e[2]; }
+      else if (ne == 2) { in_sym = e[0]; end = e[1]; out_sym = in_sym; }
+      else continue;
+      {
+        int is = in_sym + 1, os = out_sym + 1, nontoken = 0; /* :263-264 */
+        if (state + 1 > state_count) goto fail;
+        if (is != os) {
+          if (os == tokend && is == eps) { /* tokenend arc, stored under epsilon */ }
+          else if (os == eps) nontoken = 1;
+          else goto fail; /* unsupported transition */
+        } else if (is == tokend) continue;
+        else if (is == eps) goto fail;
+        else if (is >= 0 && is < sig_cap && sig_is_mcs[is]) continue;
+        if (is >= 0 && is < tr_syms) {
+          TR(state + 1, is).used = 1; TR(state + 1, is).end = end + 1; TR(state + 1, is).nontoken = nontoken;
+        }
+        if (final == 1) { TR(state + 1, fin).used = 1; TR(state + 1, fin).end = 0; TR(state + 1, fin).nontoken = 0; }
+      }
+      continue;
+    }
+  }
+  if (state_count < 0 || eps < 1 || !tr) goto fail;
+  {
+    /* ToMatrix, matrix.go:30-99 */
+    int max = idt != -1 ? idt : 0;
+    for (int k = 1; k <= sigma_count && k < sig_cap; k++) if (sig_rune[k] && k > max) max = k;
+    const uint64_t N = (uint64_t)state_count, S = (uint64_t)max + 1;
+    m = (orc_model *)calloc(1, sizeof *m);
+    m->kind = ORC_KIND_MATRIX;
+    m->epsilon = eps; m->unknown = unk; m->identity = idt; m->state_count = (uint32_t)N; m->sigma_count = (int)S;
+    m->array_len = (N + 1) * S;
+    m->array = (uint32_t *)calloc((size_t)m->array_len, 4);
+    for (int i = 0; i < 256; i++) m->sigma_ascii[i] = idt != -1 ? idt : 0; /* :43-48: zero-valued without identity */
+    {
+      uint32_t *runes = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(sigma_count + 1));
+      int *syms = (int *)malloc(sizeof(int) * (size_t)(sigma_count + 1));
+      int k2 = 0;
+      for (int k = 1; k <= sigma_count && k < sig_cap; k++)
+        if (sig_rune[k]) { if (sig_rune[k] < 256) m->sigma_ascii[sig_rune[k]] = k; runes[k2] = sig_rune[k]; syms[k2] = k; k2++; }
+      build_sigma(m, runes, syms, k2);
+      free(runes); free(syms);
+    }
+    /* transitions reachable from state 1 only (:76-96) */
+    char *seen = (char *)calloc((size_t)state_count + 2, 1);
+    int *stack = (int *)malloc(sizeof(int) * (size_t)(state_count + 2));
+    int sp = 0;
+    stack[sp++] = 1; seen[1] = 1;
+    while (sp > 0) {
+      int s0 = stack[--sp];
+      for (int a = 1; a < tr_syms; a++) {
+        fedge *e2 = &TR(s0, a);
+        if (!e2->used) continue;
+        if ((uint64_t)(a - 1) * N + (uint64_t)s0 < m->array_len)
+          m->array[(uint64_t)(a - 1) * N + (uint64_t)s0] = (uint32_t)e2->end | (e2->nontoken ? FIRSTBIT : 0u);
+        if (e2->end >= 1 && e2->end <= state_count && !seen[e2->end]) { seen[e2->end] = 1; stack[sp++] = e2->end; }
+      }
+    }
+    free(seen); free(stack);
+  }
+  free(tr); free(sig_rune); free(sig_is_mcs);
+  return m;
+fail:
+  free(tr); free(sig_rune); free(sig_is_mcs);
+  return NULL;
+#undef TR
+#undef SIG_ENSURE
+}
+
+/* fomafile.go:56-75 LoadFomaFile + ToMatrix */
+orc_model *orc_load_foma_file(const char *path) {
+  gzFile f = gzopen(path, "rb");
+  if (!f) return NULL;
+  size_t cap = 1 << 20, n = 0;
+  uint8_t *raw = (uint8_t *)malloc(cap);
+  for (;;) {
+    if (n == cap) { cap *= 2; raw = (uint8_t *)realloc(raw, cap); }
+    int k = gzread(f, raw + n, (unsigned)(cap - n));
+    if (k < 0) { gzclose(f); free(raw); return NULL; }
+    if (k == 0) break;
+    n += (size_t)k;
+  }
+  int direct = gzdirect(f);
+  gzclose(f);
+  orc_model *m = direct ? NULL : orc_parse_foma(raw, n);
+  free(raw);
+  return m;
+}

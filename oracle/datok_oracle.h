@@ -50,6 +50,9 @@ typedef struct orc_model orc_model;
 orc_model *orc_load_file(const char *path);
 /* matrix.go:235-337 ParseMatrix / datok.go:621-729 ParseDatok on raw bytes. */
 orc_model *orc_parse(const uint8_t *raw, size_t n);
+/* fomafile.go:56-450 LoadFomaFile/ParseFoma + matrix.go:30-99 ToMatrix: Foma text net -> matrix. */
+orc_model *orc_load_foma_file(const char *path);
+orc_model *orc_parse_foma(const uint8_t *raw, size_t n);
 void orc_free_model(orc_model *m);
 const char *orc_type(const orc_model *m); /* matrix.go:102, datok.go:252 */
 

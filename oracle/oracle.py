@@ -62,6 +62,8 @@ def lib():
         L = C.CDLL(_LIB)
         L.orc_load_file.restype = C.c_void_p
         L.orc_load_file.argtypes = [C.c_char_p]
+        L.orc_load_foma_file.restype = C.c_void_p
+        L.orc_load_foma_file.argtypes = [C.c_char_p]
         L.orc_parse.restype = C.c_void_p
         L.orc_parse.argtypes = [C.c_char_p, C.c_size_t]
         L.orc_free_model.argtypes = [C.c_void_p]
@@ -106,7 +108,9 @@ class Model:
 
     def __init__(self, path=None, raw=None):
         L = lib()
-        if path is not None:
+        if path is not None and str(path).endswith(".fst"):
+            self._h = L.orc_load_foma_file(os.fsencode(path))   # LoadFomaFile(...).ToMatrix()
+        elif path is not None:
             self._h = L.orc_load_file(os.fsencode(path))
         else:
             self._h = L.orc_parse(raw, len(raw))
@@ -123,6 +127,9 @@ class Model:
 
     def type(self):
         return lib().orc_type(self._h).decode()
+
+    def sigma_ascii(self):
+        return np.ctypeslib.as_array(lib().orc_sigma_ascii(self._h), shape=(256,))
 
     def array(self):
         n = self.info["array_len"] * (2 if self.info["kind"] == 1 else 1)

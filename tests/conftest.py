@@ -19,9 +19,11 @@ def pytest_configure(config):
 def oracle_models():
     """Lazily loaded oracle models keyed by fixture file name."""
     from oracle import oracle as O
+    from goldens import model_file
     cache = {}
 
     def get(name):
+        name = model_file(name)
         if name not in cache:
             cache[name] = O.Model(os.path.join(MODELS, name))
         return cache[name]

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from conftest import MODELS
-from goldens import failed_checks, golden_strings, load_cases
+from goldens import failed_checks, golden_strings, load_cases, model_file
 from parity import assert_batch_equals_oracle
 
 pytestmark = pytest.mark.gpu
@@ -22,6 +22,7 @@ def gpu():
     cache = {}
 
     def get(name):
+        name = model_file(name)   # `fst:` goldens: the Foma net itself, converted by the loader
         if name not in cache:
             cache[name] = datok_amd.load_tokenizer_file(os.path.join(MODELS, name))
             assert cache[name] is not None
@@ -94,6 +95,21 @@ def test_matok_datok_equivalence(gpu):
     assert a == b and a.count(b"\n") > 130
 
 
+def test_foma_nets_load_like_their_matok(gpu, oracle_models):
+    """LoadFomaFile(...).ToMatrix() on the device (fomafile.go:56-450, matrix.go:30-99): the net and the
+    .matok the reference built from it give the same tokenizer."""
+    from datok_amd import corpus
+    for stem in ("tokenizer_de", "clitic_test", "simpletok"):
+        a, b = gpu(stem + ".fst"), gpu(stem + ".matok")
+        assert a.type() == "MATOK"
+        ia, ib = a.info, b.info
+        assert {k: ia[k] for k in ia if k != "device_bytes"} == {k: ib[k] for k in ib if k != "device_bytes"}
+    text, off = corpus.german_docs(256, 4096, seed=21)
+    res, tot = run_batch(gpu("tokenizer_de.fst"), text, off)
+    assert tot["n_flagged"] == 0
+    assert_batch_equals_oracle(oracle_models("tokenizer_de.matok"), res, text, off)
+
+
 # ------------------------------------------------------------ batch vs oracle
 def test_config1_simpletok_1k(gpu, oracle_models):
     from datok_amd import corpus
@@ -161,7 +177,9 @@ def _edge_docs():
 
 
 @pytest.mark.parametrize("model", ["tokenizer_de.matok", "tokenizer_en.matok", "clitic_test.matok",
-                                   "simpletok.matok", "simpletok.datok", "tokenizer_de.datok"])
+                                   "simpletok.matok", "simpletok.datok", "tokenizer_de.datok",
+                                   # Foma nets converted by the loader; the first two have no identity symbol
+                                   "bauamt.fst", "wahlamt.fst", "ignorable_mcs.fst"])
 @pytest.mark.parametrize("flags,chunk,warm", [(0, 0, 64), (NEWLINE_AFTER_EOT, 0, 64), (0, 16, 64),
                                               (NEWLINE_AFTER_EOT, 32, 8), (0, 64, 0)])
 def test_edge_documents(gpu, oracle_models, model, flags, chunk, warm):
