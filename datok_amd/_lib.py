@@ -22,7 +22,8 @@ EXPORTS = [
     "dtk_batch_run", "dtk_batch_sync", "dtk_batch_stream", "dtk_batch_totals",
     "dtk_batch_set_profiling", "dtk_batch_stage_ms", "dtk_batch_set_chunking",
     "dtk_batch_result_device", "dtk_batch_result_host", "dtk_transduce", "dtk_free",
-    "dtk_foma_to_matok",
+    "dtk_foma_to_matok", "dtk_transduce_replay", "dtk_batch_render_device", "dtk_batch_render_host",
+    "dtk_batch_status_host",
 ]
 
 
@@ -48,6 +49,10 @@ class ResultView(C.Structure):
                 ("tok_bstart", C.c_void_p), ("tok_bend", C.c_void_p),
                 ("sent", C.c_void_p), ("text_tok_end", C.c_void_p), ("text_sent_end", C.c_void_p),
                 ("status", C.c_void_p), ("events", C.c_void_p), ("events_open", C.c_void_p)]
+
+
+class RenderView(C.Structure):
+    _fields_ = [("bytes", C.c_void_p), ("doc_off", C.c_void_p), ("total", C.c_uint64)]
 
 
 class DatokGpuError(RuntimeError):
@@ -113,6 +118,10 @@ def lib():
     L.dtk_batch_result_device.argtypes = [vp, C.POINTER(ResultView)]
     L.dtk_batch_result_host.argtypes = [vp, C.POINTER(ResultView)]
     L.dtk_transduce.argtypes = [vp, C.c_char_p, sz, u32, C.POINTER(vp), C.POINTER(sz), C.POINTER(u32)]
+    L.dtk_transduce_replay.argtypes = L.dtk_transduce.argtypes
+    L.dtk_batch_render_device.argtypes = [vp, u32, C.POINTER(RenderView)]
+    L.dtk_batch_render_host.argtypes = [vp, u32, C.POINTER(RenderView)]
+    L.dtk_batch_status_host.argtypes = [vp, vp, u32]
     L.dtk_foma_to_matok.argtypes = [vp, C.c_size_t, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.dtk_foma_to_matok.restype = C.c_int
     L.dtk_free.argtypes = [vp]

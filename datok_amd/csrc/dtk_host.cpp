@@ -714,12 +714,22 @@ struct dtk_batch {
   uint32_t last_flags = 0;
   uint64_t *d_tok_off = nullptr, *d_sent_off = nullptr, *d_text_off = nullptr;
   uint64_t *d_tok_cnt = nullptr, *d_sent_cnt = nullptr, *d_text_cnt = nullptr;  // per-document counts
-  uint64_t *d_totals = nullptr;  // [0..3] scan totals, [4] walk steps, [5] documents to repair (u32)
+  uint64_t *d_totals = nullptr;  // [0..3] scan totals, [4] walk steps, [5] documents to repair (u32), [6] invalid UTF-8 bytes
   uint64_t *h_totals = nullptr;  // pinned
   // outputs (grown on demand, never inside a run unless a re-launch is needed)
   uint64_t tok_cap = 0, sent_cap = 0, text_cap = 0;
   int32_t *d_rstart = nullptr, *d_rend = nullptr, *d_sent = nullptr;
   uint32_t *d_bstart = nullptr, *d_bend = nullptr, *d_ttok = nullptr, *d_tsent = nullptr;
+  uint32_t *d_sbefore = nullptr, *d_ts_end = nullptr, *d_doc_ns = nullptr;  // renderer inputs (compact)
+  // device rendering of the writer output (dtk_batch_render): workspace + output, grown on demand
+  uint64_t *d_rws = nullptr;  uint64_t rws_cap = 0;   // scans, tile sums, per-text regions (u64 words)
+  uint64_t *d_out_off = nullptr;
+  uint8_t *d_out = nullptr;   uint64_t out_cap = 0;
+  uint64_t out_total = 0;
+  uint64_t n_invalid = 0;     // invalid UTF-8 bytes of the last run (each prints as U+FFFD, 3 bytes)
+  uint32_t render_flags = 0xFFFFFFFFu;  // flags of the rendering held in d_out (none)
+  std::vector<uint8_t> h_out;
+  std::vector<uint64_t> h_out_off;
   // optional stage timing
   bool profiling = false;
   hipEvent_t ev[DTK_N_STAGES + 1] = {};
@@ -747,6 +757,7 @@ static int alloc_outputs(dtk_batch *b, uint64_t tok, uint64_t sent, uint64_t tex
     if ((rc = grow(b->d_rend, tok))) return rc;
     if ((rc = grow(b->d_bstart, tok))) return rc;
     if ((rc = grow(b->d_bend, tok))) return rc;
+    if ((rc = grow(b->d_sbefore, tok))) return rc;
     b->tok_cap = tok;
   }
   if (sent > b->sent_cap) {
@@ -756,6 +767,7 @@ static int alloc_outputs(dtk_batch *b, uint64_t tok, uint64_t sent, uint64_t tex
   if (text > b->text_cap) {
     if ((rc = grow(b->d_ttok, text))) return rc;
     if ((rc = grow(b->d_tsent, text))) return rc;
+    if ((rc = grow(b->d_ts_end, text))) return rc;
     b->text_cap = text;
   }
   return DTK_OK;
@@ -791,6 +803,8 @@ extern "C" int dtk_batch_create(uint64_t max_bytes, uint32_t max_docs, dtk_batch
   B_TRY(hipMalloc((void **)&b->d_tok_off, ((uint64_t)max_docs + 1) * 8));
   B_TRY(hipMalloc((void **)&b->d_sent_off, ((uint64_t)max_docs + 1) * 8));
   B_TRY(hipMalloc((void **)&b->d_text_off, ((uint64_t)max_docs + 1) * 8));
+  B_TRY(hipMalloc((void **)&b->d_doc_ns, ((uint64_t)max_docs + 1) * 4));
+  B_TRY(hipMalloc((void **)&b->d_out_off, ((uint64_t)max_docs + 1) * 8));
 
   B_TRY(hipHostMalloc((void **)&b->h_totals, 8 * 8, hipHostMallocDefault));
 #undef B_TRY
@@ -809,7 +823,8 @@ extern "C" void dtk_batch_free(dtk_batch *b) {
                   b->d_lane_doc, b->d_lane_cnt, b->d_lane_start, b->d_lane_end, b->d_lane_plan,
                   b->d_tok_off,
                   b->d_sent_off, b->d_text_off, b->d_rstart, b->d_rend, b->d_sent,
-                  b->d_bstart, b->d_bend, b->d_ttok, b->d_tsent};
+                  b->d_bstart, b->d_bend, b->d_ttok, b->d_tsent,
+                  b->d_sbefore, b->d_ts_end, b->d_doc_ns, b->d_rws, b->d_out_off, b->d_out};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (b->h_totals) (void)hipHostFree(b->h_totals);
@@ -972,6 +987,7 @@ static int launch_compact2(dtk_batch *b) {
   a.tok_rstart = b->d_rstart; a.tok_rend = b->d_rend;
   a.tok_bstart = b->d_bstart; a.tok_bend = b->d_bend;
   a.sent = b->d_sent; a.text_tok_end = b->d_ttok; a.text_sent_end = b->d_tsent;
+  a.tok_sbefore = b->d_sbefore; a.text_s_end = b->d_ts_end; a.doc_ns = b->d_doc_ns;
   a.tok_cap = b->tok_cap; a.sent_cap = b->sent_cap; a.text_cap = b->text_cap;
   b->last_args = a;
   if (dtk_launch_compact(&a, 2, b->stream)) return hip_fail(hipGetLastError(), "compact pass 2");
@@ -1011,7 +1027,7 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
   }
   STAGE(1);
   if (dtk_launch_symbolize(b->d_text, b->d_off, b->n_docs, b->total, &m->sig, b->d_sym,
-                           b->d_text == b->d_text_own, b->d_blk_doc, s))
+                           b->d_text == b->d_text_own, b->d_blk_doc, (unsigned long long *)(b->d_totals + 6), s))
     return hip_fail(hipGetLastError(), "symbolize");
   STAGE(2);
   DtkWalkArgs w = walk_args(b);
@@ -1047,6 +1063,7 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
   HIP_TRY(hipMemcpyAsync(b->h_totals, b->d_totals, 8 * 8, hipMemcpyDeviceToHost, s));
   b->ran = true;
   b->totals_valid = false;
+  b->render_flags = 0xFFFFFFFFu;
   return DTK_OK;
 }
 
@@ -1106,6 +1123,7 @@ static int finish(dtk_batch *b) {
     HIP_TRY(hipStreamSynchronize(s));
   }
   const uint64_t nt = b->h_totals[0], ns = b->h_totals[1], nx = b->h_totals[2];
+  b->n_invalid = b->h_totals[6];
   if (nt > b->tok_cap || ns > b->sent_cap || nx > b->text_cap) {
     int rc = alloc_outputs(b, nt + nt / 8 + 16, ns + ns / 8 + 16, nx + nx / 8 + 16);
     if (rc != DTK_OK) return rc;
@@ -1132,6 +1150,14 @@ extern "C" int dtk_batch_totals(dtk_batch *b, dtk_totals *out) {
   int rc = finish(b);
   if (rc != DTK_OK) return rc;
   *out = b->totals;
+  return DTK_OK;
+}
+
+extern "C" int dtk_batch_status_host(dtk_batch *b, uint32_t *status, uint32_t n) {
+  if (!b || !status || n > b->n_docs) return DTK_E_ARG;
+  int rc = finish(b);
+  if (rc != DTK_OK) return rc;
+  if (n) HIP_TRY(hipMemcpy(status, b->d_status, (size_t)n * 4, hipMemcpyDeviceToHost));
   return DTK_OK;
 }
 
@@ -1175,6 +1201,84 @@ extern "C" int dtk_batch_result_host(dtk_batch *b, dtk_result_view *o) {
   o->tok_bstart = b->h_bstart.data(); o->tok_bend = b->h_bend.data();
   o->sent = b->h_sent.data(); o->text_tok_end = b->h_ttok.data(); o->text_sent_end = b->h_tsent.data();
   o->status = b->h_status.data(); o->events = b->h_events.data(); o->events_open = b->h_events_b.data();
+  return DTK_OK;
+}
+
+// ---------------------------------------------------------------- rendering
+//
+// NewTokenWriter(w, bits) for every document of the batch, on the device (dtk_render.hip).
+static int render(dtk_batch *b, uint32_t bits) {
+  int rc = finish(b);
+  if (rc != DTK_OK) return rc;
+  if (bits & ~31u) return DTK_E_ARG;
+  // the positions were computed under the run's NEWLINE_AFTER_EOT rule (token_writer.go:66-68)
+  if ((bits ^ b->last_flags) & DTK_NEWLINE_AFTER_EOT) return DTK_E_ARG;
+  bits &= 15u;
+  if (b->render_flags == bits) return DTK_OK;
+  hipStream_t s = b->stream;
+  const uint64_t nt = b->totals.n_tokens, ns = b->totals.n_sent, nx = b->totals.n_texts, nd = b->n_docs;
+  const uint64_t tt = dtk_render_tiles(nt), st = dtk_render_tiles(ns);
+  const uint64_t words = 2 * (nt + 1) + (ns + 1) + 2 * tt + st + (nd + 1) + 4 * (nx + 1) + 8;
+  if (words > b->rws_cap) {
+    if (b->d_rws) HIP_TRY(hipFree(b->d_rws));
+    b->d_rws = nullptr; b->rws_cap = 0;
+    HIP_TRY(hipMalloc((void **)&b->d_rws, (words + words / 8) * 8));
+    b->rws_cap = words + words / 8;
+  }
+  DtkRenderArgs R{};
+  R.text = b->d_text; R.doc_off = b->d_off; R.n_docs = b->n_docs; R.flags = bits;
+  R.tok_off = b->d_tok_off; R.sent_off = b->d_sent_off; R.text_off = b->d_text_off;
+  R.n_tok = nt; R.n_sent = ns; R.n_text = nx;
+  R.rstart = b->d_rstart; R.rend = b->d_rend; R.sent = b->d_sent;
+  R.bstart = b->d_bstart; R.bend = b->d_bend; R.sbefore = b->d_sbefore;
+  R.ttok = b->d_ttok; R.tsent = b->d_tsent; R.ts_end = b->d_ts_end; R.doc_ns = b->d_doc_ns;
+  R.sym = b->n_invalid ? b->d_sym : nullptr;
+  uint64_t *q = b->d_rws;
+  R.A = q; q += nt + 1; R.P = q; q += nt + 1; R.Q = q; q += ns + 1;
+  R.blkA = q; q += tt; R.blkP = q; q += tt; R.blkQ = q; q += st;
+  R.ns_off = q; q += nd + 1;
+  R.tx_base = q; q += nx + 1; R.tx_stream = q; q += nx + 1; R.tx_pos = q; q += nx + 1; R.tx_sent = q; q += nx + 1;
+  R.out_off = b->d_out_off;
+  if (dtk_launch_render(&R, 0, s)) return hip_fail(hipGetLastError(), "render sizes");
+  HIP_TRY(hipMemcpyAsync(b->h_totals + 7, R.tx_base + nx, 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  const uint64_t total = b->h_totals[7];
+  if (total > b->out_cap) {
+    if (b->d_out) HIP_TRY(hipFree(b->d_out));
+    b->d_out = nullptr; b->out_cap = 0;
+    HIP_TRY(hipMalloc((void **)&b->d_out, total + total / 8 + 256));
+    b->out_cap = total + total / 8 + 256;
+  }
+  R.out = b->d_out; R.out_total = total;
+  if (total) {
+    HIP_TRY(hipMemsetAsync(b->d_out, '\n', total, s));  // every separator that is not a space
+    if (dtk_launch_render(&R, 1, s)) return hip_fail(hipGetLastError(), "render bytes");
+  }
+  b->out_total = total;
+  b->render_flags = bits;
+  return DTK_OK;
+}
+
+extern "C" int dtk_batch_render_device(dtk_batch *b, uint32_t bits, dtk_render_view *o) {
+  if (!b || !o) return DTK_E_ARG;
+  int rc = render(b, bits);
+  if (rc != DTK_OK) return rc;
+  o->bytes = b->d_out; o->doc_off = b->d_out_off; o->total = b->out_total;
+  return DTK_OK;
+}
+
+extern "C" int dtk_batch_render_host(dtk_batch *b, uint32_t bits, dtk_render_view *o) {
+  if (!b || !o) return DTK_E_ARG;
+  int rc = render(b, bits);
+  if (rc != DTK_OK) return rc;
+  b->h_out.resize(std::max<uint64_t>(b->out_total, 1));
+  b->h_out_off.resize((size_t)b->n_docs + 1);
+  if (b->out_total)
+    HIP_TRY(hipMemcpyAsync(b->h_out.data(), b->d_out, b->out_total, hipMemcpyDeviceToHost, b->stream));
+  HIP_TRY(hipMemcpyAsync(b->h_out_off.data(), b->d_out_off, ((size_t)b->n_docs + 1) * 8, hipMemcpyDeviceToHost,
+                         b->stream));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  o->bytes = b->h_out.data(); o->doc_off = b->h_out_off.data(); o->total = b->out_total;
   return DTK_OK;
 }
 

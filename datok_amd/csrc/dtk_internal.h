@@ -152,8 +152,34 @@ struct DtkCompactArgs {
   uint32_t *tok_bstart, *tok_bend;
   int32_t *sent;
   uint32_t *text_tok_end, *text_sent_end;
+  // for the renderer: SentenceEnd calls (of the document) before each Token / TextEnd call, and per document
+  uint32_t *tok_sbefore, *text_s_end, *doc_ns;
   const uint64_t *totals;   // [0..2] tokens, sentence ints, texts (written by the scan)
   uint64_t tok_cap, sent_cap, text_cap;
+};
+
+// NewTokenWriter's byte output on the device (dtk_render.hip)
+struct DtkRenderArgs {
+  const uint8_t *text;
+  const uint64_t *doc_off;
+  uint32_t n_docs;
+  uint32_t flags;  // TOKENS 1, SENTENCES 2, TOKEN_POS 4, SENTENCE_POS 8
+  const uint64_t *tok_off, *sent_off, *text_off;  // CSR rows per document
+  uint64_t n_tok, n_sent, n_text;
+  const int32_t *rstart, *rend, *sent;
+  const uint32_t *bstart, *bend, *sbefore;  // per token
+  const uint32_t *ttok, *tsent, *ts_end;    // per text: tokens / sentence ints / SentenceEnd calls up to its TextEnd
+  const uint32_t *doc_ns;                   // SentenceEnd calls per document
+  const uint16_t *sym;                      // symbol stream; non-null only if the batch has invalid UTF-8 bytes
+  // workspace
+  uint64_t *A, *P, *Q;           // exclusive scans: surface bytes, position digits (n_tok+1), sentence digits (n_sent+1)
+  uint64_t *blkA, *blkP, *blkQ;  // per-tile sums
+  uint64_t *ns_off;              // n_docs+1
+  uint64_t *tx_base, *tx_stream, *tx_pos, *tx_sent;  // n_text+1
+  // output
+  uint64_t *out_off;  // n_docs+1
+  uint8_t *out;
+  uint64_t out_total;
 };
 
 #ifdef __cplusplus
@@ -162,13 +188,15 @@ extern "C" {
 // launchers (dtk_kernels.hip); stream is a hipStream_t
 int dtk_launch_symbolize(const uint8_t *text, const uint64_t *doc_off, uint32_t n_docs,
                          uint64_t total, const struct DtkSigmaDev *sig, uint16_t *sym, int padded,
-                         const uint32_t *blk_doc, void *stream);
+                         const uint32_t *blk_doc, unsigned long long *n_invalid, void *stream);
 #define DTK_SYM_BLOCK_BYTES 4096u  // input bytes per symbolise block (blk_doc granularity)
 int dtk_launch_walk(const struct DtkTableDev *tab, const struct DtkWalkArgs *args, void *stream);
 int dtk_launch_spec(const struct DtkTableDev *tab, const struct DtkWalkArgs *args,
                     const struct DtkSpecArgs *spec, int stage, uint32_t cmp_mask, uint32_t *redo_out,
                     uint32_t *n_bad, void *stream);
 int dtk_launch_compact(const struct DtkCompactArgs *args, int pass, void *stream);
+int dtk_launch_render(const struct DtkRenderArgs *args, int stage, void *stream);
+uint32_t dtk_render_tiles(uint64_t n);
 int dtk_launch_scan3(const uint64_t *ca, const uint64_t *cb, const uint64_t *cc, uint64_t *a, uint64_t *b,
                      uint64_t *c, uint32_t n_docs, uint64_t *totals, const uint32_t *status, void *stream);
 #ifdef __cplusplus

@@ -88,7 +88,8 @@ __global__ __launch_bounds__(WAVE) void k_symbolize(const uint8_t *__restrict__ 
                                                     const uint64_t *__restrict__ doc_off,
                                                     uint32_t n_docs, uint64_t total, DtkSigmaDev sig,
                                                     uint16_t *__restrict__ sym,
-                                                    const uint32_t *__restrict__ blk_doc) {
+                                                    const uint32_t *__restrict__ blk_doc,
+                                                    unsigned long long *__restrict__ n_invalid) {
   __shared__ uint16_t lut[128];       // symbol | class | START for the runes < 128 (index = byte)
   __shared__ uint16_t lat[256];       // symbol | class for runes < 256 (heavy path, Latin-1)
   __shared__ uint32_t s_runes[256];   // sigma map (runes >= 256)
@@ -231,6 +232,8 @@ __global__ __launch_bounds__(WAVE) void k_symbolize(const uint8_t *__restrict__ 
           }
         }
         sym[g] = (uint16_t)(a_cls | ((wd - 1) << DTK_SYM_W_SHIFT) | (start ? DTK_SYM_START : 0u));
+        // a byte that decodes to U+FFFD with width 1 prints as three bytes (the renderer's slow path)
+        if (start && wd == 1u) atomicAdd(n_invalid, 1ull);
       }
     }
     __syncthreads();  // the queue is reused by the next half
@@ -1138,6 +1141,7 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
         A.tok_bend[tok_base + k] = P;
         A.tok_rstart[tok_base + k] = rstart;
         A.tok_rend[tok_base + k] = rend;
+        A.tok_sbefore[tok_base + k] = sBeforeEnd;  // SentenceEnd calls before this Token call
       }
       uint64_t si = sent_base + cNSent + excl;
       if (si + c <= sent_lim) {
@@ -1152,6 +1156,7 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
         if (ti < text_lim) {
           A.text_tok_end[ti] = te;
           A.text_sent_end[ti] = cNSent + excl + s1_valid;
+          A.text_s_end[ti] = sBeforeEnd;  // SentenceEnd calls before this TextEnd call
         } else status |= ST_INTERNAL;
       }
       if (f & EV_E_EOF) {
@@ -1159,6 +1164,7 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
         if (ti < text_lim) {
           A.text_tok_end[ti] = tokLate;
           A.text_sent_end[ti] = cNSent + excl + c;
+          A.text_s_end[ti] = sBeforeEnd + sLate;
         } else status |= ST_INTERNAL;
       }
       if (isEnd && tok_base + k >= tok_lim) status |= ST_INTERNAL;
@@ -1199,6 +1205,7 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
       sred |= ST_INTERNAL;
     sred &= ST_INTERNAL;  // everything else was reported by the walk already
     if (sred) atomicOr(&A.status[d], sred);
+    A.doc_ns[d] = cNSev;  // SentenceEnd calls of this document (for rendering)
   }
 }
 
@@ -1245,17 +1252,17 @@ __global__ __launch_bounds__(1024) void k_scan3(const uint64_t *ca, const uint64
 
 extern "C" int dtk_launch_symbolize(const uint8_t *text, const uint64_t *doc_off, uint32_t n_docs,
                                     uint64_t total, const DtkSigmaDev *sig, uint16_t *sym, int padded,
-                                    const uint32_t *blk_doc, void *stream) {
+                                    const uint32_t *blk_doc, unsigned long long *n_invalid, void *stream) {
   if (total == 0 || n_docs == 0) return 0;
   const uint32_t blocks = (uint32_t)((total + SYM_BLOCK_BYTES - 1) / SYM_BLOCK_BYTES);
   // ALIGNED4 may read up to 3 bytes past `total`: true for the batch's own (padded) buffer;
   // a caller-owned device buffer only qualifies when its size is a multiple of 4
   if ((((uintptr_t)text) & 3u) == 0 && (padded || (total & 3u) == 0))
     hipLaunchKernelGGL(k_symbolize<true>, dim3(blocks), dim3(WAVE), 0, (hipStream_t)stream, text, doc_off, n_docs,
-                       total, *sig, sym, blk_doc);
+                       total, *sig, sym, blk_doc, n_invalid);
   else
     hipLaunchKernelGGL(k_symbolize<false>, dim3(blocks), dim3(WAVE), 0, (hipStream_t)stream, text, doc_off, n_docs,
-                       total, *sig, sym, blk_doc);
+                       total, *sig, sym, blk_doc, n_invalid);
   return (int)hipGetLastError();
 }
 

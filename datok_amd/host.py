@@ -6,7 +6,7 @@ import sys
 import numpy as np
 
 from . import _lib
-from ._lib import ModelInfo, ResultView, Totals, check, lib
+from ._lib import ModelInfo, RenderView, ResultView, Totals, check, lib
 
 # token_writer.go:17-25
 TOKENS, SENTENCES, TOKEN_POS, SENTENCE_POS, NEWLINE_AFTER_EOT = 1, 2, 4, 8, 16
@@ -203,10 +203,12 @@ class Tokenizer:
         tw.Flush()                              # `defer w.Flush()`, matrix.go:374
         return True
 
-    def transduce_bytes(self, text: bytes, flags=SIMPLE):
-        """dtk_transduce(): rendering done by the C++ host mirror. Returns (output, status)."""
+    def transduce_bytes(self, text: bytes, flags=SIMPLE, replay=False):
+        """dtk_transduce(): walked and rendered on the device; replay=True: dtk_transduce_replay(), the
+        event bytes replayed into the C++ host mirror of NewTokenWriter. Returns (output, status)."""
         out, n, st = C.c_void_p(), C.c_size_t(), C.c_uint32()
-        check(lib().dtk_transduce(self._h, text, len(text), flags, C.byref(out), C.byref(n), C.byref(st)))
+        fn = lib().dtk_transduce_replay if replay else lib().dtk_transduce
+        check(fn(self._h, text, len(text), flags, C.byref(out), C.byref(n), C.byref(st)))
         try:
             return C.string_at(out, n.value), st.value
         finally:
@@ -325,6 +327,20 @@ class Batch:
         v = ResultView()
         check(lib().dtk_batch_result_device(self._h, C.byref(v)), "dtk_batch_result_device")
         return v
+
+    def render_device(self, flags=SIMPLE) -> RenderView:
+        """NewTokenWriter(w, flags) for every document, left on the device (pointers + total)."""
+        v = RenderView()
+        check(lib().dtk_batch_render_device(self._h, flags, C.byref(v)), "dtk_batch_render_device")
+        return v
+
+    def render(self, flags=SIMPLE):
+        """Returns (bytes, doc_off): bytes[doc_off[d]:doc_off[d+1]] is what the reference writes for document d."""
+        v = RenderView()
+        check(lib().dtk_batch_render_host(self._h, flags, C.byref(v)), "dtk_batch_render_host")
+        off = np.frombuffer((C.c_char * ((self.n_docs + 1) * 8)).from_address(v.doc_off), dtype=np.uint64).copy()
+        data = C.string_at(v.bytes, v.total) if v.total else b""
+        return data, off
 
     def result(self) -> BatchResult:
         v = ResultView()

@@ -187,6 +187,8 @@ typedef struct {
   const uint8_t *events_open;
 } dtk_result_view;
 int dtk_batch_result_device(dtk_batch *b, dtk_result_view *out);
+/* status words of the first n documents, copied to the caller's array */
+int dtk_batch_status_host(dtk_batch *b, uint32_t *status, uint32_t n);
 /* Copies the arrays to host memory owned by the batch (valid until the next
  * run / free) and returns host pointers in the same struct. */
 int dtk_batch_result_host(dtk_batch *b, dtk_result_view *out);
@@ -205,13 +207,32 @@ enum {
   DTK_EV_E_EOF = 64      /* final TextEnd (matrix.go:690-691) */
 };
 
+/* ---- NewTokenWriter(w, bits) (token_writer.go:36-175) for every document of the batch, rendered on
+ *      the device: bytes[doc_off[d] .. doc_off[d+1]) is exactly what the reference writes to w for
+ *      document d (surfaces + "\n", "\n" per sentence / text end, position lines) -- SIMPLE gives the
+ *      stream of Transduce (matrix.go:340-342).  Call after dtk_batch_run; `bits` may differ from the
+ *      run's flags except for DTK_NEWLINE_AFTER_EOT.  The view is owned by the batch (valid until the
+ *      next run / render / free).  Documents flagged DTK_ST_EMPTY_TEXT make the reference panic in
+ *      position modes; their bytes are unspecified. ---- */
+typedef struct {
+  const uint8_t *bytes;
+  const uint64_t *doc_off; /* n_docs + 1 */
+  uint64_t total;
+} dtk_render_view;
+int dtk_batch_render_device(dtk_batch *b, uint32_t bits, dtk_render_view *out);
+int dtk_batch_render_host(dtk_batch *b, uint32_t bits, dtk_render_view *out);
+
 /* ---- drop-in for Tokenizer.Transduce / TransduceTokenWriter with a stock
- *      NewTokenWriter(w, bits): renders what the reference writes to w for ONE
- *      stream (the walk runs on the GPU, the rendering of the returned offsets
- *      is host code, token_writer.go:36-175).  *out is malloc'd; free with
+ *      NewTokenWriter(w, bits): what the reference writes to w for ONE stream
+ *      (matrix.go:340-348, token_writer.go:36-175).  dtk_transduce walks and renders on the
+ *      GPU; dtk_transduce_replay walks on the GPU and replays the event bytes into the
+ *      closures of the C++ mirror of NewTokenWriter (include/datok.hpp) -- the path of a custom
+ *      TokenWriter.  Both give the same bytes.  *out is malloc'd; free with
  *      dtk_free.  Returns 0 (the reference's `true`) or a negative code. ---- */
 int dtk_transduce(const dtk_model *m, const uint8_t *text, size_t n, uint32_t bits,
                   char **out, size_t *out_len, uint32_t *status);
+int dtk_transduce_replay(const dtk_model *m, const uint8_t *text, size_t n, uint32_t bits,
+                         char **out, size_t *out_len, uint32_t *status);
 void dtk_free(void *p);
 
 #ifdef __cplusplus

@@ -13,6 +13,7 @@ from parity import assert_batch_equals_oracle
 pytestmark = pytest.mark.gpu
 
 TOKENS, SENTENCES, TOKEN_POS, SENTENCE_POS, NEWLINE_AFTER_EOT = 1, 2, 4, 8, 16
+SIMPLE = TOKENS | SENTENCES
 
 
 @pytest.fixture(scope="module")
@@ -237,6 +238,83 @@ def test_rendered_output_all_flag_combinations(gpu, oracle_models):
                     continue
                 got, st = gpu(model).transduce_bytes(t.encode(), flags)
                 assert (got, st) == (exp, 0), (model, flags, t)
+                # the closure-replay path (custom TokenWriter) prints the same bytes
+                assert gpu(model).transduce_bytes(t.encode(), flags, replay=True) == (exp, 0)
+
+
+# ------------------------------------------------- NewTokenWriter on the device
+ALL_MODELS = ["tokenizer_de.matok", "tokenizer_en.matok", "clitic_test.matok", "simpletok.matok",
+              "simpletok.datok", "tokenizer_de.datok", "bauamt.fst", "ignorable_mcs.fst"]
+
+
+@pytest.mark.parametrize("model", ALL_MODELS)
+def test_device_rendering_edge_documents(gpu, oracle_models, model):
+    """dtk_batch_render_*: bytes[doc_off[d]:doc_off[d+1]] == what NewTokenWriter(w, bits) prints for
+    document d (token_writer.go:36-175), for all 16 writer modes x NEWLINE_AFTER_EOT, on the edge
+    documents (EOT texts, invalid UTF-8, empty documents, window overflows excluded by status)."""
+    import datok_amd
+    from datok_amd import corpus, ST_IRREGULAR
+    docs = _edge_docs()
+    text, off = corpus.concat_docs(docs)
+    om = oracle_models(model)
+    checked = 0
+    with datok_amd.Batch(len(text), len(docs)) as b:
+        b.set_input(text, off)
+        for nl in (0, NEWLINE_AFTER_EOT):
+            b.run(gpu(model), nl)
+            status = b.result().status
+            for bits in range(16):
+                data, o = b.render(bits | nl)
+                assert o[0] == 0 and o[-1] == len(data) and np.all(np.diff(o.astype(np.int64)) >= 0)
+                for d, doc in enumerate(docs):
+                    exp, est = om.transduce(doc, bits | nl)
+                    if est or (int(status[d]) & ~datok_amd.ST_EMPTY_TEXT):
+                        continue   # the reference panics / out of contract (flagged)
+                    got = data[int(o[d]):int(o[d + 1])]
+                    assert got == exp, (model, bits | nl, d, doc[:80], got[:120], exp[:120])
+                    checked += 1
+    assert checked > 16 * 2 * 200
+
+
+@pytest.mark.parametrize("model", ["tokenizer_de.matok", "tokenizer_de.datok"])
+def test_device_rendering_config2(gpu, oracle_models, model):
+    """The bench batch rendered on the device: SIMPLE (= Transduce, matrix.go:340-342) and everything
+    at once, every document against the oracle; rendering twice with other bits needs no new run."""
+    import datok_amd
+    from datok_amd import corpus
+    text, off = corpus.german_docs(4096, 4096, seed=2)
+    raw = text.tobytes()
+    om = oracle_models(model)
+    with datok_amd.Batch(len(text), len(off) - 1) as b:
+        b.set_input(text, off)
+        b.run(gpu(model), 0)
+        for bits in (SIMPLE, 15, TOKEN_POS):
+            data, o = b.render(bits)
+            for d in range(len(off) - 1):
+                exp, est = om.transduce(raw[int(off[d]):int(off[d + 1])], bits)
+                assert est == 0 and data[int(o[d]):int(o[d + 1])] == exp, (bits, d)
+        with pytest.raises(datok_amd.DatokGpuError):
+            b.render(SIMPLE | NEWLINE_AFTER_EOT)   # positions were computed without that rule
+
+
+def test_device_rendering_single_long_stream(gpu, oracle_models):
+    """One 2 MiB stream with in-document EOT texts (a DeReKo-style stream, Readme.md:54)."""
+    import datok_amd
+    from datok_amd import corpus
+    text, off = corpus.german_docs(512, 4096, seed=31)
+    raw = bytearray(text.tobytes())
+    for d in range(1, 512):        # every 4 KiB: "\x04\n" ends a text
+        raw[d * 4096 - 2:d * 4096] = b"\x04\n"
+    raw = bytes(raw)
+    one = np.frombuffer(raw, dtype=np.uint8)
+    tok, om = gpu("tokenizer_de.matok"), oracle_models("tokenizer_de.matok")
+    with datok_amd.Batch(len(one), 1) as b:
+        b.set_input(one, np.array([0, len(one)], dtype=np.uint64))
+        b.run(tok, NEWLINE_AFTER_EOT)
+        for bits in (SIMPLE, 15, SENTENCE_POS):
+            data, o = b.render(bits | NEWLINE_AFTER_EOT)
+            exp, est = om.transduce(raw, bits | NEWLINE_AFTER_EOT)
+            assert est == 0 and data == exp
 
 
 def test_size_independent_properties_large(gpu):
