@@ -71,8 +71,9 @@ def build(force=False):
     srcs = [os.path.join(src_dir, f) for f in os.listdir(src_dir)
             if f.endswith((".hip", ".cpp", ".h"))]
     srcs += [os.path.join(_HERE, "..", "include", f) for f in ("datok_gpu.h", "datok.hpp")]
-    if (not force and os.path.exists(LIB_PATH)
-            and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
+    cli = os.path.join(_HERE, "datok")     # the command line (csrc/datok_cli.cpp), built by the same Makefile
+    if (not force and os.path.exists(LIB_PATH) and os.path.exists(cli)
+            and all(min(os.path.getmtime(LIB_PATH), os.path.getmtime(cli)) >= os.path.getmtime(s) for s in srcs)):
         return LIB_PATH
     subprocess.check_call(["make", "-C", src_dir, "-s"])
     return LIB_PATH

@@ -245,10 +245,23 @@ class GpuTokenizer final : public Tokenizer {
   std::string Type() const override { return dtk_model_type(m_); }
   const dtk_model *model() const { return m_; }
 
-  // matrix.go:340-342 / datok.go:769-771
-  bool Transduce(std::istream &r, std::ostream &w) override {
-    auto tw = NewTokenWriter(w, SIMPLE);
-    return TransduceTokenWriter(r, *tw);
+  // matrix.go:340-342 / datok.go:769-771: TransduceTokenWriter(r, NewTokenWriter(w, SIMPLE)).
+  // The stock writer's bytes are rendered on the device (dtk_transduce); a custom writer goes
+  // through TransduceTokenWriter below.
+  bool Transduce(std::istream &r, std::ostream &w) override { return TransduceBits(r, w, SIMPLE); }
+
+  // TransduceTokenWriter(r, NewTokenWriter(w, bits)) for any Bits
+  bool TransduceBits(std::istream &r, std::ostream &w, Bits bits) {
+    std::string text((std::istreambuf_iterator<char>(r)), std::istreambuf_iterator<char>());
+    char *out = nullptr;
+    size_t n = 0;
+    last_status_ = 0;
+    if (dtk_transduce(m_, (const uint8_t *)text.data(), text.size(), (uint32_t)bits, &out, &n, &last_status_) != DTK_OK)
+      return false;
+    w.write(out, (std::streamsize)n);
+    w.flush();
+    dtk_free(out);
+    return true;
   }
 
   // matrix.go:348-698 / datok.go:781-1135: one stream = one document.

@@ -89,3 +89,22 @@ def test_product_convert_rejections():
         assert e.value.code == code, bad
     with pytest.raises(_lib.DatokGpuError):
         datok_amd.foma_to_matok(b"plain text, not gzip")     # fomafile.go:63-67
+
+
+def test_cli_convert(tmp_path):
+    """`datok convert -i x.fst -o x.matok` (cmd/datok.go:50-70) over the C-ABI; host only."""
+    import subprocess
+    import datok_amd
+    datok_amd.build()
+    exe = os.path.join(os.path.dirname(datok_amd.__file__), "datok")
+    out = tmp_path / "clitic.matok"
+    r = subprocess.run([exe, "convert", "-i", os.path.join(MODELS, "clitic_test.fst"), "-o", str(out)],
+                       capture_output=True)
+    assert r.returncode == 0 and r.stdout == b"File successfully converted.\n"
+    assert gzip.decompress(out.read_bytes()) == gzip.decompress(_read("clitic_test.matok"))
+    r = subprocess.run([exe, "convert", "--foma=" + os.path.join(MODELS, "simpletok.fst"),
+                        "--tokenizer=" + str(out), "-d"], capture_output=True)
+    assert r.returncode == 1 and b"double array" in r.stderr           # ToDoubleArray is not provided
+    r = subprocess.run([exe, "convert", "-i", str(tmp_path / "missing.fst"), "-o", str(out)], capture_output=True)
+    assert r.returncode == 1 and b"Unable to load foma file" in r.stderr
+    assert subprocess.run([exe, "tokenize", "-t", "x"], capture_output=True).returncode == 1   # missing <input>

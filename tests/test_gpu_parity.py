@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import MODELS
+from conftest import MODELS, ROOT
 from goldens import failed_checks, golden_strings, load_cases, model_file
 from parity import assert_batch_equals_oracle
 
@@ -343,3 +343,80 @@ def test_size_independent_properties_large(gpu):
     a3 = res3.doc(16384 - 1 - d)
     a1 = res.doc(d)
     assert np.array_equal(a1["tok_rstart"], a3["tok_rstart"]) and np.array_equal(a1["sent"], a3["sent"])
+
+
+# ------------------------------------------------------------ CLI and C++ mirror
+def test_cli_tokenize(oracle_models, tmp_path):
+    """`datok tokenize -t tok [flags] file|-` (cmd/datok.go:74-133): flag -> Bits mapping and output."""
+    import subprocess
+    import datok_amd
+    exe = os.path.join(os.path.dirname(datok_amd.__file__), "datok")
+    text = "Der alte Mann. Er ging! „Wirklich?“\n\x04\nZweiter Text, z.B. hier.\n\x04\n".encode()
+    inp = tmp_path / "in.txt"
+    inp.write_bytes(text)
+    model = os.path.join(MODELS, "tokenizer_de.matok")
+    om = oracle_models("tokenizer_de.matok")
+    for args, bits in [([], SIMPLE), (["-p"], SIMPLE | TOKEN_POS), (["--no-tokens", "--sentence-positions"], SENTENCES | SENTENCE_POS),
+                       (["--no-sentences", "--token-positions", "--newline-after-eot"], TOKENS | TOKEN_POS | NEWLINE_AFTER_EOT),
+                       (["--no-tokens", "--no-sentences"], 0)]:
+        exp, est = om.transduce(text, bits)
+        assert est == 0
+        r = subprocess.run([exe, "tokenize", "-t", model] + args + [str(inp)], capture_output=True)
+        assert r.returncode == 0 and r.stdout == exp, (args, r.stdout, r.stderr)
+    r = subprocess.run([exe, "tokenize", "--tokenizer=" + model, "-"], input=text, capture_output=True)
+    assert r.returncode == 0 and r.stdout == om.transduce(text, SIMPLE)[0]
+    r = subprocess.run([exe, "tokenize", "-t", str(tmp_path / "none.matok"), str(inp)], capture_output=True)
+    assert r.returncode == 1 and b"Unable to load file" in r.stderr
+
+
+def test_cpp_mirror_end_to_end(oracle_models, tmp_path):
+    """include/datok.hpp: LoadTokenizerFile / Transduce (device rendering) / TransduceTokenWriter with a
+    custom writer (closure replay) -- the Go surface of fomafile.go:29-33 in C++."""
+    import subprocess
+    import datok_amd
+    lib = datok_amd.build()
+    src = tmp_path / "e2e.cpp"
+    src.write_text(r'''
+#include <fstream>
+#include <iostream>
+#include <sstream>
+#include "datok.hpp"
+int main(int argc, char **argv) {
+  auto tok = datok::LoadTokenizerFile(argv[1]);
+  if (!tok) return 3;
+  std::cout << tok->Type() << "\n";
+  { std::ifstream in(argv[2], std::ios::binary); if (!tok->Transduce(in, std::cout)) return 4; }
+  std::cout << "--\n";
+  { std::ifstream in(argv[2], std::ios::binary);
+    auto tw = datok::NewTokenWriter(std::cout, datok::TOKENS | datok::TOKEN_POS | datok::SENTENCE_POS);
+    if (!tok->TransduceTokenWriter(in, *tw)) return 5; }
+  std::cout << "--\n";
+  { std::ifstream in(argv[2], std::ios::binary);
+    datok::TokenWriter tw;   // a custom writer: counts calls
+    int nt = 0, ns = 0, ne = 0;
+    tw.Token = [&](int, const std::vector<datok::rune> &) { nt++; };
+    tw.SentenceEnd = [&](int) { ns++; };
+    tw.TextEnd = [&](int) { ne++; };
+    tw.Flush = [] { return 0; };
+    if (!tok->TransduceTokenWriter(in, tw)) return 6;
+    std::cout << nt << " " << ns << " " << ne << "\n"; }
+  return datok::LoadTokenizerFile("/nonexistent.matok") ? 7 : 0;
+}
+''')
+    exe = tmp_path / "e2e"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           lib, "-Wl,-rpath," + os.path.dirname(lib)])
+    text = "Der alte Mann. Er ging!\n\x04\nNoch ein Text.".encode()
+    inp = tmp_path / "in.txt"
+    inp.write_bytes(text)
+    om = oracle_models("tokenizer_de.matok")
+    r = subprocess.run([str(exe), os.path.join(MODELS, "tokenizer_de.matok"), str(inp)], capture_output=True)
+    assert r.returncode == 0, r.stderr
+    simple = om.transduce(text, SIMPLE)[0]
+    full = om.transduce(text, TOKENS | TOKEN_POS | SENTENCE_POS)[0]
+    head, rest = r.stdout.split(b"\n", 1)
+    assert head == b"MATOK"
+    a, b, c = rest.split(b"--\n")
+    assert a == simple and b == full
+    nt, ns, ne = (int(x) for x in c.split())
+    assert nt == simple.count(b"\n") - ns - ne and ne == 2 and ns >= 3
