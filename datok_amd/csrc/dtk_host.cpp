@@ -300,6 +300,7 @@ static int layout_matrix(dtk_model *m, const std::vector<uint32_t> &arr) {
   m->tab.entry_bytes = (uint32_t)cell_bytes;
   m->tab.fused = fused ? 1u : 0u;
   m->tab.ident_guard = m->unknown_used ? (uint32_t)m->identity : 0xFFFFFFFFu;
+  m->tab.plain_walk = getenv("DATOK_PLAIN_WALK") ? 1u : 0u;
   m->tab.stride = stride;
   m->tab.n_states = (uint32_t)N;
   m->tab.n_eps = m->n_eps_states;

@@ -277,6 +277,7 @@ struct MatrixFusedTrans {
   const uint32_t *tab;
   uint32_t stride, n_eps, start;
   uint32_t ident_guard;  // the identity symbol if the model has arcs on `unknown`, else no symbol
+  uint32_t plain_walk;   // 1: use the general loop even where the lean one applies (A/B, tests)
   static constexpr bool FUSED = true;
   __device__ __forceinline__ uint32_t start_state() const { return start; }
   __device__ __forceinline__ uint32_t start_aux() const { return 0; }
@@ -618,6 +619,170 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
   steps_out = my_steps;
 }
 
+// The same walk for the common case -- matrix with fused cells, no arc on the `unknown` symbol
+// anywhere (so the sticky `ok` and the retry of matrix.go:478-485 have no observable effect) --
+// written for a short instruction stream: one symbol prefetch and one cell load per iteration,
+// lane state in plain integers, and one guarded block for everything that happens less than
+// once per token (hard fail, EOT, end of input, end of the chunk, the window limit).
+// Behaviour is identical to walk_lane<MatrixFusedTrans, true, MODE> for such models.
+template <int MODE>
+__device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uint16_t *__restrict__ sym_base,
+                                           uint64_t off, uint32_t len, DtkLaneState init, uint32_t stop_pos,
+                                           EventSink &sink, uint32_t epsilon, uint32_t cap, DtkLaneState &fin,
+                                           uint32_t &st_out, uint32_t &steps_out) {
+  const uint16_t *__restrict__ s = sym_base + off;
+  const uint32_t *__restrict__ tab = tr.tab;
+  const uint32_t stride = tr.stride, n_eps = tr.n_eps;
+  uint32_t t = init.t;
+  uint32_t p = init.p, tp = init.p, bs = init.p, hi = init.p, rl = 0;
+  uint32_t eps_t = 0, eps_p = 0, eps_rl = 0;
+  uint32_t sent_end = (init.flags & LANE_F_SENT) ? 1u : 0u, text_end = (init.flags & LANE_F_TEXT) ? 1u : 0u;
+  uint32_t any_tok = init.p > 0 ? 1u : 0u;
+  uint32_t has_tok = (init.p > 0 && !text_end) ? 1u : 0u;
+  uint32_t retry = 0;  // 1: this iteration looks up the epsilon arc of `t` at p and reads no rune
+  uint32_t a = 0, w = 1, st = 0, it = 0;
+  bool eot = false;
+  fin.p = 0xFFFFFFFFu; fin.t = 0; fin.aux = 0; fin.flags = 0;
+  bool stopped = false, done = false;
+  uint32_t en = s[p];  // entry of the rune at p (prefetched one iteration ahead)
+  do {
+    it++;
+    const bool at_eof = !retry && p >= len;
+    if (!retry) {
+      a = en & DTK_SYM_MASK;
+      w = ((en >> DTK_SYM_W_SHIFT) & 3u) + 1u;
+      eot = ((en >> DTK_SYM_CLS_SHIFT) & 3u) == 1u;
+    }
+    if (at_eof) {
+      // reader at EOF: the drain of matrix.go:650-668
+      const bool he = t <= n_eps;
+      const bool bt = !he && eps_t != 0;
+      t = bt ? eps_t : t;
+      p = bt ? eps_p : p; rl = bt ? eps_rl : rl;
+      eps_t = bt ? 0u : eps_t;
+      retry = 1;
+      done = !he && !bt;
+      eot = false;
+    }
+    a = retry ? epsilon : a;
+    // the rune the next iteration reads: behind this one, or this position again after an epsilon step
+    const uint32_t pn = retry ? p : p + w;
+    const uint32_t en_next = s[pn];
+    hi = max(hi, pn);                                   // matrix.go:388-408
+    const bool he = !retry && t <= n_eps;               // matrix.go:442-454
+    eps_t = he ? t : eps_t; eps_p = he ? p : eps_p; eps_rl = he ? rl : eps_rl;
+    const uint32_t x = tab[(size_t)t * stride + a];
+    const uint32_t tgt = x & 0x7FFFu;
+    const bool nontoken = (x & 0x8000u) != 0;
+    const bool fz = (int32_t)x < 0;
+    const bool comp = fz && (MODE == MODE_DOC || p < stop_pos) && !done;
+    const bool plain = (int32_t)x > 0 && !done;
+    const bool advance = plain && !retry;               // matrix.go:579-591
+    const bool epsE = (plain && retry) || comp;         // an epsilon arc is taken at p
+    const bool flush = epsE && p > tp;                  // matrix.go:565-572
+    const bool sentE = epsE && p <= tp;                 // matrix.go:573-576
+    const bool fail = !plain && !comp && !done;
+    const bool backtrack = fail && !retry && eps_t != 0;  // matrix.go:487-497
+    const bool hardfail = fail && !backtrack;
+    if (MODE != MODE_START) {
+      if (flush) sink.template token<true>(tp, p, rl, (sent_end | text_end | (any_tok ^ 1u)) != 0);
+      if (sentE) sink.sentence(p, has_tok != 0);
+    }
+    const uint32_t bs_old = bs;
+    any_tok = flush ? 1u : any_tok;
+    has_tok = flush ? 1u : has_tok;
+    sent_end = flush ? 0u : (sentE ? 1u : sent_end);
+    text_end = flush ? 0u : text_end;
+    const bool skip = nontoken && ((advance && p == tp) || comp);  // matrix.go:584-588
+    const bool rewE = flush && !comp;                   // the rewind of a plain epsilon step ends a chunk
+    const uint32_t p_old = p;
+    p = (advance || comp) ? pn : p;
+    rl = skip ? 0u : (comp ? 1u : (advance ? rl + 1u : rl));
+    tp = skip ? p : (comp ? p_old : tp);
+    tp = rewE ? p : tp;
+    rl = rewE ? 0u : rl;
+    bs = flush ? p_old : bs;
+    // the epsilon slot: dropped by a backtrack, a rewind and a fused cell; a fused cell remembers
+    // the state it read its rune in if that state has an epsilon arc
+    const uint32_t via = (x >> 16) & 0x7FFFu;
+    const bool he2 = comp && via <= n_eps;
+    t = backtrack ? eps_t : ((plain || comp) ? tgt : t);
+    p = backtrack ? eps_p : p; rl = backtrack ? eps_rl : rl;
+    eps_t = (backtrack || flush || comp) ? (he2 ? via : 0u) : eps_t;
+    eps_p = he2 ? p_old : eps_p; eps_rl = he2 ? 0u : eps_rl;
+    retry = backtrack ? 1u : 0u;
+    en = en_next;
+    // everything that happens less than once per token
+    const bool eot_now = (advance || comp) && eot;      // matrix.go:593-605
+    const bool over = flush && hi - bs_old > DTK_WINDOW;
+    const bool at_stop = rewE && MODE != MODE_DOC && p >= stop_pos;
+    if (hardfail || eot_now || over || at_stop || it > cap) {
+      if (hardfail) {  // matrix.go:499-552: drop what is buffered as a token, restart at state 1
+        if (a == epsilon) { st |= ST_BAD_MODEL; done = true; }
+        else {
+          if (p <= tp) { p = pn; rl++; } else { en = s[p]; }  // matrix.go:515-516 / the rune is read again
+          if (MODE != MODE_START)
+            sink.template token<true>(tp, p, rl, (sent_end | text_end | (any_tok ^ 1u)) != 0);
+          any_tok = 1; has_tok = 1; sent_end = 0; text_end = 0;
+          if (hi - bs > DTK_WINDOW && count_runes(s, bs, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
+          t = tr.start; eps_t = 0;
+          tp = p; bs = p; rl = 0;
+          if (MODE != MODE_DOC && p >= stop_pos) {
+            fin.p = p; fin.t = t; fin.aux = 0;
+            fin.flags = (init.flags & LANE_F_OK);
+            stopped = true; done = true;
+          }
+        }
+      }
+      if (over && count_runes(s, bs_old, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
+      if (eot_now) {
+        if (MODE != MODE_START) sink.template eot<true>(p, sent_end == 0u, has_tok != 0);
+        has_tok = 0;  // TextEnd: pos = pos[:0] (token_writer.go:158)
+        sent_end = 1; text_end = 1;
+        eps_t = 0;    // matrix.go:601 rewinds
+        if (hi - bs > DTK_WINDOW && count_runes(s, bs, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
+        tp = p; bs = p; rl = 0;
+      }
+      if ((at_stop || (eot_now && MODE != MODE_DOC && p >= stop_pos)) && !done) {
+        fin.p = p; fin.t = t; fin.aux = 0;
+        fin.flags = (sent_end ? LANE_F_SENT : 0u) | (text_end ? LANE_F_TEXT : 0u) | (init.flags & LANE_F_OK);
+        stopped = true; done = true;
+      }
+      if (it > cap && !done) { st |= ST_STEP_LIMIT; done = true; }
+    }
+  } while (!done);
+
+  if (!stopped && !(st & (ST_STEP_LIMIT | ST_BAD_MODEL))) {
+    if (hi - bs > DTK_WINDOW && count_runes(s, bs, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
+    if (MODE != MODE_START) {
+      if (p > tp) {  // matrix.go:671-678
+        sink.template token<true>(tp, p, rl, (sent_end | text_end | (any_tok ^ 1u)) != 0);
+        sent_end = 0; text_end = 0;
+        has_tok = 1;
+      }
+      sink.tail(p, sent_end != 0, text_end != 0, has_tok != 0);  // matrix.go:683-691
+    }
+  }
+  st_out = st;
+  steps_out = (stopped || (st & (ST_STEP_LIMIT | ST_BAD_MODEL))) ? it : it - 1u;  // lookups of an active lane
+}
+
+// the lean walk applies: fused cells and no arc on `unknown` (ident_guard is then "no symbol")
+template <typename TRANS, bool IS_MATRIX, int MODE>
+__device__ __forceinline__ void walk_any(const TRANS &tr, const uint16_t *__restrict__ sym_base, uint64_t off,
+                                         uint32_t len, DtkLaneState init, uint32_t stop_pos, EventSink &sink,
+                                         uint32_t epsilon, uint32_t unknown, uint32_t identity, uint32_t cap,
+                                         DtkLaneState &fin, uint32_t &st_out, uint32_t &steps_out) {
+  if constexpr (TRANS::FUSED) {
+    if (tr.ident_guard == 0xFFFFFFFFu && !tr.plain_walk) {
+      walk_fused<MODE>(tr, sym_base, off, len, init, stop_pos, sink, epsilon, cap, fin, st_out, steps_out);
+      return;
+    }
+  }
+  walk_lane<TRANS, IS_MATRIX, MODE>(tr, sym_base, off, len, init, stop_pos, sink, epsilon, unknown, identity, cap,
+                                    fin, st_out, steps_out);
+}
+
 __device__ __forceinline__ uint32_t step_cap(uint32_t factor, uint32_t len) {
   unsigned long long c = (unsigned long long)factor * ((unsigned long long)len + 2ull);
   return c > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)c;
@@ -644,7 +809,7 @@ __global__ __launch_bounds__(WAVE) void k_walk_doc(TRANS tr, DtkWalkArgs A, uint
     sink.init(A.evA + evb, A.evB + evb, A.tlen + evb, 0u, 0xFFFFFFFFu);
     DtkLaneState init{0u, tr.start_state(), tr.start_aux(), 0u}, fin;
     uint32_t st;
-    walk_lane<TRANS, IS_MATRIX, MODE_DOC>(tr, A.sym, off, len, init, 0u, sink, epsilon, unknown,
+    walk_any<TRANS, IS_MATRIX, MODE_DOC>(tr, A.sym, off, len, init, 0u, sink, epsilon, unknown,
                                           identity, step_cap(A.step_factor, len), fin, st, steps);
     A.status[d] = st | sink.st;
     A.tok_cnt[d] = sink.c_tok; A.sent_cnt[d] = sink.c_sent; A.text_cnt[d] = sink.c_text;
@@ -691,7 +856,7 @@ __global__ __launch_bounds__(WAVE) void k_spec_start(TRANS tr, DtkWalkArgs A, Dt
           EventSink sink;
           sink.init(nullptr, nullptr, nullptr, 0u, 0u);
           uint32_t st;
-          walk_lane<TRANS, IS_MATRIX, MODE_START>(tr, A.sym, off, len, init, kc, sink, epsilon, unknown,
+          walk_any<TRANS, IS_MATRIX, MODE_START>(tr, A.sym, off, len, init, kc, sink, epsilon, unknown,
                                                   identity, step_cap(A.step_factor, len), rec, st, steps);
         }
         // sp == 0: the walk from the true initial state; its first sync point at/after kc
@@ -699,7 +864,7 @@ __global__ __launch_bounds__(WAVE) void k_spec_start(TRANS tr, DtkWalkArgs A, Dt
           EventSink sink;
           sink.init(nullptr, nullptr, nullptr, 0u, 0u);
           uint32_t st;
-          walk_lane<TRANS, IS_MATRIX, MODE_START>(tr, A.sym, off, len, rec, kc, sink, epsilon, unknown,
+          walk_any<TRANS, IS_MATRIX, MODE_START>(tr, A.sym, off, len, rec, kc, sink, epsilon, unknown,
                                                   identity, step_cap(A.step_factor, len), rec, st, steps);
         }
       }
@@ -810,7 +975,7 @@ __global__ __launch_bounds__(WAVE) void k_spec_walk(TRANS tr, DtkWalkArgs A, Dtk
         const uint64_t evb = DTK_EV_BASE(off, d);
         sink.init(A.evA + evb, A.evB + evb, A.tlen + evb, init.p, pl.wend);
         uint32_t st = 0;
-        walk_lane<TRANS, IS_MATRIX, MODE_CHUNK>(tr, A.sym, off, len, init, pl.stop, sink, epsilon, unknown,
+        walk_any<TRANS, IS_MATRIX, MODE_CHUNK>(tr, A.sym, off, len, init, pl.stop, sink, epsilon, unknown,
                                                 identity, step_cap(A.step_factor, len), fin, st, steps);
         if (sink.dropped) fin.flags |= LANE_F_DROPPED;
         cnt.tok = sink.c_tok; cnt.sent = sink.c_sent; cnt.text = sink.c_text; cnt.status = st | sink.st;
@@ -1270,7 +1435,8 @@ template <typename F>
 static int with_trans(const DtkTableDev *tab, F &&f) {
   if (tab->kind == DTK_KIND_MATRIX) {
     if (tab->fused) {
-      MatrixFusedTrans tr{(const uint32_t *)tab->tab, tab->stride, tab->n_eps, tab->start, tab->ident_guard};
+      MatrixFusedTrans tr{(const uint32_t *)tab->tab, tab->stride, tab->n_eps, tab->start, tab->ident_guard,
+                          tab->plain_walk};
       f(tr, std::true_type{});
     } else if (tab->entry_bytes == 2) {
       MatrixTrans<uint16_t> tr{(const uint16_t *)tab->tab, tab->stride, tab->n_eps, tab->start};
