@@ -644,15 +644,15 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
   bool eot = false;
   fin.p = 0xFFFFFFFFu; fin.t = 0; fin.aux = 0; fin.flags = 0;
   bool stopped = false, done = false;
-  uint32_t en = s[p];  // entry of the rune at p (prefetched one iteration ahead)
+  // symbol stream in aligned groups of 4 entries (8-byte loads): the current group and the next
+  // one are held in registers, so a lane issues one load per ~4 runes
+  const uint32_t o3 = (uint32_t)(off & 3u);
+  const uint64_t *__restrict__ sq = reinterpret_cast<const uint64_t *>(sym_base + (off - o3));
+  uint32_t grp = 0xFFFFFFFEu;
+  uint64_t q_cur = 0, q_next = 0;
   do {
     it++;
     const bool at_eof = !retry && p >= len;
-    if (!retry) {
-      a = en & DTK_SYM_MASK;
-      w = ((en >> DTK_SYM_W_SHIFT) & 3u) + 1u;
-      eot = ((en >> DTK_SYM_CLS_SHIFT) & 3u) == 1u;
-    }
     if (at_eof) {
       // reader at EOF: the drain of matrix.go:650-668
       const bool he = t <= n_eps;
@@ -662,12 +662,25 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
       eps_t = bt ? 0u : eps_t;
       retry = 1;
       done = !he && !bt;
-      eot = false;
+    }
+    {
+      // also in an epsilon iteration (which reads no rune): the group of the position the next
+      // iteration reads is then already on its way
+      const uint32_t i = p + o3, g = i >> 2;
+      if (g != grp) {
+        q_cur = (g == grp + 1u) ? q_next : sq[g];
+        q_next = sq[g + 1u];
+        grp = g;
+      }
+      const uint32_t e = (uint32_t)(q_cur >> ((i & 3u) * 16u)) & 0xFFFFu;
+      if (!retry) {
+        a = e & DTK_SYM_MASK;
+        w = ((e >> DTK_SYM_W_SHIFT) & 3u) + 1u;
+        eot = ((e >> DTK_SYM_CLS_SHIFT) & 3u) == 1u;
+      }
     }
     a = retry ? epsilon : a;
-    // the rune the next iteration reads: behind this one, or this position again after an epsilon step
-    const uint32_t pn = retry ? p : p + w;
-    const uint32_t en_next = s[pn];
+    const uint32_t pn = retry ? p : p + w;  // behind this rune
     hi = max(hi, pn);                                   // matrix.go:388-408
     const bool he = !retry && t <= n_eps;               // matrix.go:442-454
     eps_t = he ? t : eps_t; eps_p = he ? p : eps_p; eps_rl = he ? rl : eps_rl;
@@ -711,7 +724,6 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
     eps_t = (backtrack || flush || comp) ? (he2 ? via : 0u) : eps_t;
     eps_p = he2 ? p_old : eps_p; eps_rl = he2 ? 0u : eps_rl;
     retry = backtrack ? 1u : 0u;
-    en = en_next;
     // everything that happens less than once per token
     const bool eot_now = (advance || comp) && eot;      // matrix.go:593-605
     const bool over = flush && hi - bs_old > DTK_WINDOW;
@@ -720,7 +732,7 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
       if (hardfail) {  // matrix.go:499-552: drop what is buffered as a token, restart at state 1
         if (a == epsilon) { st |= ST_BAD_MODEL; done = true; }
         else {
-          if (p <= tp) { p = pn; rl++; } else { en = s[p]; }  // matrix.go:515-516 / the rune is read again
+          if (p <= tp) { p = pn; rl++; }  // matrix.go:515-516
           if (MODE != MODE_START)
             sink.template token<true>(tp, p, rl, (sent_end | text_end | (any_tok ^ 1u)) != 0);
           any_tok = 1; has_tok = 1; sent_end = 0; text_end = 0;
