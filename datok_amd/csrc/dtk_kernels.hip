@@ -644,14 +644,24 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
   bool eot = false;
   fin.p = 0xFFFFFFFFu; fin.t = 0; fin.aux = 0; fin.flags = 0;
   bool stopped = false, done = false;
-  // symbol stream in aligned groups of 4 entries (8-byte loads): the current group and the next
-  // one are held in registers, so a lane issues one load per ~4 runes
+  // Symbol stream in aligned groups of 4 entries (8-byte loads).  q_cur is the group of the rune
+  // this iteration reads, q_next the one behind it.  Refills are issued one iteration early (for
+  // the position the lane reaches if its rune is consumed) and land in ld_a / ld_b; they are
+  // moved into q_cur / q_next at the top of the next iteration, i.e. after that iteration's
+  // cell load has been waited for anyway -- a refill never stalls the wave by itself.
   const uint32_t o3 = (uint32_t)(off & 3u);
   const uint64_t *__restrict__ sq = reinterpret_cast<const uint64_t *>(sym_base + (off - o3));
-  uint32_t grp = 0xFFFFFFFEu;
-  uint64_t q_cur = 0, q_next = 0;
+  uint32_t grp = (p + o3) >> 2;
+  uint64_t q_cur = sq[grp], q_next = sq[grp + 1u];
+  uint64_t ld_a = 0, ld_b = 0;
+  uint32_t pend = 0;  // 1: ld_b -> q_next;  2: also ld_a -> q_cur
   do {
     it++;
+    if (pend) {
+      q_next = ld_b;
+      q_cur = pend == 2u ? ld_a : q_cur;
+      pend = 0;
+    }
     const bool at_eof = !retry && p >= len;
     if (at_eof) {
       // reader at EOF: the drain of matrix.go:650-668
@@ -663,28 +673,37 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
       retry = 1;
       done = !he && !bt;
     }
-    {
-      // also in an epsilon iteration (which reads no rune): the group of the position the next
-      // iteration reads is then already on its way
-      const uint32_t i = p + o3, g = i >> 2;
-      if (g != grp) {
-        q_cur = (g == grp + 1u) ? q_next : sq[g];
-        q_next = sq[g + 1u];
-        grp = g;
-      }
-      const uint32_t e = (uint32_t)(q_cur >> ((i & 3u) * 16u)) & 0xFFFFu;
-      if (!retry) {
-        a = e & DTK_SYM_MASK;
-        w = ((e >> DTK_SYM_W_SHIFT) & 3u) + 1u;
-        eot = ((e >> DTK_SYM_CLS_SHIFT) & 3u) == 1u;
-      }
+    if (!retry) {
+      const uint32_t e = (uint32_t)(q_cur >> (((p + o3) & 3u) * 16u)) & 0xFFFFu;
+      a = e & DTK_SYM_MASK;
+      w = ((e >> DTK_SYM_W_SHIFT) & 3u) + 1u;
+      eot = ((e >> DTK_SYM_CLS_SHIFT) & 3u) == 1u;
     }
     a = retry ? epsilon : a;
-    const uint32_t pn = retry ? p : p + w;  // behind this rune
+    const uint32_t x = tab[(size_t)t * stride + a];
+    // while the cell is on its way: the group of the position the next rune is read from (behind
+    // this rune; after a backtrack the epsilon iteration, which reads no rune, does this for the
+    // position it returns to)
+    const uint32_t pn = retry ? p : p + w;
+    {
+      const uint32_t g = (pn + o3) >> 2;
+      if (g != grp) {
+        if (g == grp + 1u) {
+          q_cur = q_next;
+          pend = 1;
+        } else {
+          ld_a = sq[g];
+          pend = 2;
+        }
+        ld_b = sq[g + 1u];
+        grp = g;
+      }
+    }
     hi = max(hi, pn);                                   // matrix.go:388-408
     const bool he = !retry && t <= n_eps;               // matrix.go:442-454
+    const uint32_t t_now = t;
     eps_t = he ? t : eps_t; eps_p = he ? p : eps_p; eps_rl = he ? rl : eps_rl;
-    const uint32_t x = tab[(size_t)t * stride + a];
+    (void)t_now;
     const uint32_t tgt = x & 0x7FFFu;
     const bool nontoken = (x & 0x8000u) != 0;
     const bool fz = (int32_t)x < 0;
@@ -733,6 +752,9 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
         if (a == epsilon) { st |= ST_BAD_MODEL; done = true; }
         else {
           if (p <= tp) { p = pn; rl++; }  // matrix.go:515-516
+          else {  // the rune is read again: its group, now
+            grp = (p + o3) >> 2; q_cur = sq[grp]; q_next = sq[grp + 1u]; pend = 0;
+          }
           if (MODE != MODE_START)
             sink.template token<true>(tp, p, rl, (sent_end | text_end | (any_tok ^ 1u)) != 0);
           any_tok = 1; has_tok = 1; sent_end = 0; text_end = 0;
