@@ -636,9 +636,11 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
   uint32_t t = init.t;
   uint32_t p = init.p, tp = init.p, bs = init.p, hi = init.p, rl = 0;
   uint32_t eps_t = 0, eps_p = 0, eps_rl = 0;
-  uint32_t sent_end = (init.flags & LANE_F_SENT) ? 1u : 0u, text_end = (init.flags & LANE_F_TEXT) ? 1u : 0u;
-  uint32_t any_tok = init.p > 0 ? 1u : 0u;
-  uint32_t has_tok = (init.p > 0 && !text_end) ? 1u : 0u;
+  // F: 1 sentenceEnd, 2 textEnd (matrix.go:360-363), 4 some Token call happened in this document,
+  //    8 the current text has a token (what NewTokenWriter's sentB / pos need)
+  uint32_t F = (init.flags & (LANE_F_SENT | LANE_F_TEXT)) | (init.p > 0 ? 4u : 0u);
+  F |= (init.p > 0 && !(init.flags & LANE_F_TEXT)) ? 8u : 0u;
+  static_assert(LANE_F_SENT == 1u && LANE_F_TEXT == 2u, "flag layout");
   uint32_t retry = 0;  // 1: this iteration looks up the epsilon arc of `t` at p and reads no rune
   uint32_t a = 0, w = 1, st = 0, it = 0;
   bool eot = false;
@@ -655,36 +657,39 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
   uint64_t q_cur = sq[grp], q_next = sq[grp + 1u];
   uint64_t ld_a = 0, ld_b = 0;
   uint32_t pend = 0;  // 1: ld_b -> q_next;  2: also ld_a -> q_cur
-  do {
+
+  // reader at EOF: the drain of matrix.go:650-668 (checked before every rune)
+#define DTK_EOF_DRAIN()                                              \
+  if (!retry && p >= len) {                                          \
+    const bool he_ = t <= n_eps;                                     \
+    const bool bt_ = !he_ && eps_t != 0;                             \
+    t = bt_ ? eps_t : t;                                             \
+    p = bt_ ? eps_p : p; rl = bt_ ? eps_rl : rl;                     \
+    eps_t = bt_ ? 0u : eps_t;                                        \
+    retry = 1;                                                       \
+    done = !he_ && !bt_;                                             \
+  }
+  DTK_EOF_DRAIN()
+  while (!done) {
     it++;
     if (pend) {
       q_next = ld_b;
       q_cur = pend == 2u ? ld_a : q_cur;
       pend = 0;
     }
-    const bool at_eof = !retry && p >= len;
-    if (at_eof) {
-      // reader at EOF: the drain of matrix.go:650-668
-      const bool he = t <= n_eps;
-      const bool bt = !he && eps_t != 0;
-      t = bt ? eps_t : t;
-      p = bt ? eps_p : p; rl = bt ? eps_rl : rl;
-      eps_t = bt ? 0u : eps_t;
-      retry = 1;
-      done = !he && !bt;
-    }
-    if (!retry) {
+    const bool r = retry != 0;
+    if (!r) {
       const uint32_t e = (uint32_t)(q_cur >> (((p + o3) & 3u) * 16u)) & 0xFFFFu;
       a = e & DTK_SYM_MASK;
       w = ((e >> DTK_SYM_W_SHIFT) & 3u) + 1u;
       eot = ((e >> DTK_SYM_CLS_SHIFT) & 3u) == 1u;
     }
-    a = retry ? epsilon : a;
+    a = r ? epsilon : a;
     const uint32_t x = tab[(size_t)t * stride + a];
     // while the cell is on its way: the group of the position the next rune is read from (behind
     // this rune; after a backtrack the epsilon iteration, which reads no rune, does this for the
     // position it returns to)
-    const uint32_t pn = retry ? p : p + w;
+    const uint32_t pn = r ? p : p + w;
     {
       const uint32_t g = (pn + o3) >> 2;
       if (g != grp) {
@@ -700,31 +705,25 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
       }
     }
     hi = max(hi, pn);                                   // matrix.go:388-408
-    const bool he = !retry && t <= n_eps;               // matrix.go:442-454
-    const uint32_t t_now = t;
+    const bool he = !r && t <= n_eps;                   // matrix.go:442-454
     eps_t = he ? t : eps_t; eps_p = he ? p : eps_p; eps_rl = he ? rl : eps_rl;
-    (void)t_now;
     const uint32_t tgt = x & 0x7FFFu;
     const bool nontoken = (x & 0x8000u) != 0;
-    const bool fz = (int32_t)x < 0;
-    const bool comp = fz && (MODE == MODE_DOC || p < stop_pos) && !done;
-    const bool plain = (int32_t)x > 0 && !done;
-    const bool advance = plain && !retry;               // matrix.go:579-591
-    const bool epsE = (plain && retry) || comp;         // an epsilon arc is taken at p
+    const bool comp = (int32_t)x < 0 && (MODE == MODE_DOC || p < stop_pos);
+    const bool plain = (int32_t)x > 0;
+    const bool advance = plain && !r;                   // matrix.go:579-591
+    const bool epsE = (plain && r) || comp;             // an epsilon arc is taken at p
     const bool flush = epsE && p > tp;                  // matrix.go:565-572
     const bool sentE = epsE && p <= tp;                 // matrix.go:573-576
-    const bool fail = !plain && !comp && !done;
-    const bool backtrack = fail && !retry && eps_t != 0;  // matrix.go:487-497
+    const bool fail = !plain && !comp;
+    const bool backtrack = fail && !r && eps_t != 0;    // matrix.go:487-497
     const bool hardfail = fail && !backtrack;
     if (MODE != MODE_START) {
-      if (flush) sink.template token<true>(tp, p, rl, (sent_end | text_end | (any_tok ^ 1u)) != 0);
-      if (sentE) sink.sentence(p, has_tok != 0);
+      if (flush) sink.template token<true>(tp, p, rl, ((F ^ 4u) & 7u) != 0);
+      if (sentE) sink.sentence(p, (F & 8u) != 0);
     }
     const uint32_t bs_old = bs;
-    any_tok = flush ? 1u : any_tok;
-    has_tok = flush ? 1u : has_tok;
-    sent_end = flush ? 0u : (sentE ? 1u : sent_end);
-    text_end = flush ? 0u : text_end;
+    F = flush ? ((F & ~3u) | 12u) : (sentE ? (F | 1u) : F);
     const bool skip = nontoken && ((advance && p == tp) || comp);  // matrix.go:584-588
     const bool rewE = flush && !comp;                   // the rewind of a plain epsilon step ends a chunk
     const uint32_t p_old = p;
@@ -755,9 +754,8 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
           else {  // the rune is read again: its group, now
             grp = (p + o3) >> 2; q_cur = sq[grp]; q_next = sq[grp + 1u]; pend = 0;
           }
-          if (MODE != MODE_START)
-            sink.template token<true>(tp, p, rl, (sent_end | text_end | (any_tok ^ 1u)) != 0);
-          any_tok = 1; has_tok = 1; sent_end = 0; text_end = 0;
+          if (MODE != MODE_START) sink.template token<true>(tp, p, rl, ((F ^ 4u) & 7u) != 0);
+          F = 12u;
           if (hi - bs > DTK_WINDOW && count_runes(s, bs, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
           t = tr.start; eps_t = 0;
           tp = p; bs = p; rl = 0;
@@ -770,35 +768,35 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
       }
       if (over && count_runes(s, bs_old, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
       if (eot_now) {
-        if (MODE != MODE_START) sink.template eot<true>(p, sent_end == 0u, has_tok != 0);
-        has_tok = 0;  // TextEnd: pos = pos[:0] (token_writer.go:158)
-        sent_end = 1; text_end = 1;
-        eps_t = 0;    // matrix.go:601 rewinds
+        if (MODE != MODE_START) sink.template eot<true>(p, (F & 1u) == 0u, (F & 8u) != 0);
+        F = (F & 4u) | 3u;  // sentenceEnd, textEnd; TextEnd: pos = pos[:0] (token_writer.go:158)
+        eps_t = 0;          // matrix.go:601 rewinds
         if (hi - bs > DTK_WINDOW && count_runes(s, bs, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
         tp = p; bs = p; rl = 0;
       }
       if ((at_stop || (eot_now && MODE != MODE_DOC && p >= stop_pos)) && !done) {
         fin.p = p; fin.t = t; fin.aux = 0;
-        fin.flags = (sent_end ? LANE_F_SENT : 0u) | (text_end ? LANE_F_TEXT : 0u) | (init.flags & LANE_F_OK);
+        fin.flags = (F & 3u) | (init.flags & LANE_F_OK);
         stopped = true; done = true;
       }
       if (it > cap && !done) { st |= ST_STEP_LIMIT; done = true; }
     }
-  } while (!done);
+    if (!done) { DTK_EOF_DRAIN() }
+  }
+#undef DTK_EOF_DRAIN
 
   if (!stopped && !(st & (ST_STEP_LIMIT | ST_BAD_MODEL))) {
     if (hi - bs > DTK_WINDOW && count_runes(s, bs, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
     if (MODE != MODE_START) {
       if (p > tp) {  // matrix.go:671-678
-        sink.template token<true>(tp, p, rl, (sent_end | text_end | (any_tok ^ 1u)) != 0);
-        sent_end = 0; text_end = 0;
-        has_tok = 1;
+        sink.template token<true>(tp, p, rl, ((F ^ 4u) & 7u) != 0);
+        F = (F & ~3u) | 8u;
       }
-      sink.tail(p, sent_end != 0, text_end != 0, has_tok != 0);  // matrix.go:683-691
+      sink.tail(p, (F & 1u) != 0, (F & 2u) != 0, (F & 8u) != 0);  // matrix.go:683-691
     }
   }
   st_out = st;
-  steps_out = (stopped || (st & (ST_STEP_LIMIT | ST_BAD_MODEL))) ? it : it - 1u;  // lookups of an active lane
+  steps_out = it;  // lookups
 }
 
 // the lean walk applies: fused cells and no arc on `unknown` (ident_guard is then "no symbol")
