@@ -347,13 +347,13 @@ struct EventSink {
   uint32_t last_s_p, s_bits;      // position / byte of the last opening SentenceEnd
   uint32_t last_eot_p, eot_bits;  // position / byte of the last EOT pair (double array merge)
   uint32_t st;
-  bool dropped;
+  uint32_t dropped;
   // what NewTokenWriter would have collected from this lane's calls
   // (token_writer.go:72-81, 104-109, 131-159): tokens, ints of the sentence list, texts
   uint32_t c_tok, c_sent, c_text;
   __device__ __forceinline__ void init(uint8_t *a, uint8_t *b, uint32_t *tl, uint32_t wlo, uint32_t whi) {
     evA = a; evB = b; tlen = tl; lo = wlo; hi = whi;
-    last_s_p = last_eot_p = 0xFFFFFFFFu; s_bits = eot_bits = 0; st = 0; dropped = false;
+    last_s_p = last_eot_p = 0xFFFFFFFFu; s_bits = eot_bits = 0; st = 0; dropped = 0;
     c_tok = c_sent = c_text = 0;
   }
   __device__ __forceinline__ bool in_closing(uint32_t p) const { return p > lo && p <= hi; }
@@ -363,7 +363,7 @@ struct EventSink {
   // sent_first: no token since the last SentenceEnd / TextEnd (the writer's sentB)
   template <bool IS_MATRIX>
   __device__ __forceinline__ void token(uint32_t tp, uint32_t p, uint32_t rl, bool sent_first) {
-    if (!in_closing(p)) { dropped = true; return; }
+    if (!in_closing(p)) { dropped = 1; return; }
     c_tok++;
     c_sent += sent_first ? 1u : 0u;
     uint32_t bits = EV_TOK_END;
@@ -376,7 +376,7 @@ struct EventSink {
   // has_tok: the current text has a token (else the reference panics in position modes)
   template <bool IS_MATRIX>
   __device__ __forceinline__ void eot(uint32_t p, bool with_sentence, bool has_tok) {
-    if (!in_closing(p)) { dropped = true; return; }
+    if (!in_closing(p)) { dropped = 1; return; }
     c_text++;
     if (has_tok) c_sent += with_sentence ? 1u : 0u; else st |= ST_EMPTY_TEXT;
     if (!IS_MATRIX && p == last_eot_p) st |= ST_IRREGULAR;  // the same EOT consumed twice
@@ -386,7 +386,7 @@ struct EventSink {
   }
   // SentenceEnd from an epsilon arc on an empty token -- matrix.go:574-575
   __device__ __forceinline__ void sentence(uint32_t p, bool has_tok) {
-    if (!in_opening(p)) { dropped = true; return; }
+    if (!in_opening(p)) { dropped = 1; return; }
     if (has_tok) c_sent++; else st |= ST_EMPTY_TEXT;
     if (p == last_s_p) {
       if (s_bits & EV_S_EPS2) st |= ST_IRREGULAR;
@@ -401,7 +401,7 @@ struct EventSink {
   __device__ __forceinline__ void tail(uint32_t p, bool sentence_end, bool text_end, bool has_tok) {
     const uint32_t bits = (sentence_end ? 0u : EV_S_EOF) | (text_end ? 0u : EV_E_EOF);
     if (!bits) return;
-    if (!in_opening(p)) { dropped = true; return; }
+    if (!in_opening(p)) { dropped = 1; return; }
     if (!text_end) c_text++;
     if (has_tok) c_sent += sentence_end ? 0u : 1u; else st |= ST_EMPTY_TEXT;
     evB[p] = (uint8_t)(bits | (p == last_s_p ? s_bits : 0u));
@@ -642,10 +642,9 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
   F |= (init.p > 0 && !(init.flags & LANE_F_TEXT)) ? 8u : 0u;
   static_assert(LANE_F_SENT == 1u && LANE_F_TEXT == 2u, "flag layout");
   uint32_t retry = 0;  // 1: this iteration looks up the epsilon arc of `t` at p and reads no rune
-  uint32_t a = 0, w = 1, st = 0, it = 0;
-  bool eot = false;
-  fin.p = 0xFFFFFFFFu; fin.t = 0; fin.aux = 0; fin.flags = 0;
-  bool stopped = false, done = false;
+  uint32_t st = 0, it = 0;
+  fin.p = 0xFFFFFFFFu; fin.t = 0; fin.aux = 0; fin.flags = 0;  // p stays "ran to EOF" unless the lane stops
+  bool done = false;
   // Symbol stream in aligned groups of 4 entries (8-byte loads).  q_cur is the group of the rune
   // this iteration reads, q_next the one behind it.  Refills are issued one iteration early (for
   // the position the lane reaches if its rune is consumed) and land in ld_a / ld_b; they are
@@ -678,18 +677,14 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
       pend = 0;
     }
     const bool r = retry != 0;
-    if (!r) {
-      const uint32_t e = (uint32_t)(q_cur >> (((p + o3) & 3u) * 16u)) & 0xFFFFu;
-      a = e & DTK_SYM_MASK;
-      w = ((e >> DTK_SYM_W_SHIFT) & 3u) + 1u;
-      eot = ((e >> DTK_SYM_CLS_SHIFT) & 3u) == 1u;
-    }
-    a = r ? epsilon : a;
+    // the rune at p (an epsilon iteration reads none: the extracted entry is then not used)
+    const uint32_t e = (uint32_t)(q_cur >> (((p + o3) & 3u) * 16u));
+    const uint32_t a = r ? epsilon : (e & DTK_SYM_MASK);
     const uint32_t x = tab[(size_t)t * stride + a];
     // while the cell is on its way: the group of the position the next rune is read from (behind
     // this rune; after a backtrack the epsilon iteration, which reads no rune, does this for the
     // position it returns to)
-    const uint32_t pn = r ? p : p + w;
+    const uint32_t pn = r ? p : p + ((e >> DTK_SYM_W_SHIFT) & 3u) + 1u;
     {
       const uint32_t g = (pn + o3) >> 2;
       if (g != grp) {
@@ -743,12 +738,12 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
     eps_p = he2 ? p_old : eps_p; eps_rl = he2 ? 0u : eps_rl;
     retry = backtrack ? 1u : 0u;
     // everything that happens less than once per token
-    const bool eot_now = (advance || comp) && eot;      // matrix.go:593-605
+    const bool eot_now = (advance || comp) && ((e >> DTK_SYM_CLS_SHIFT) & 3u) == 1u;  // matrix.go:593-605
     const bool over = flush && hi - bs_old > DTK_WINDOW;
     const bool at_stop = rewE && MODE != MODE_DOC && p >= stop_pos;
     if (hardfail || eot_now || over || at_stop || it > cap) {
       if (hardfail) {  // matrix.go:499-552: drop what is buffered as a token, restart at state 1
-        if (a == epsilon) { st |= ST_BAD_MODEL; done = true; }
+        if (r) { st |= ST_BAD_MODEL; done = true; }
         else {
           if (p <= tp) { p = pn; rl++; }  // matrix.go:515-516
           else {  // the rune is read again: its group, now
@@ -762,7 +757,7 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
           if (MODE != MODE_DOC && p >= stop_pos) {
             fin.p = p; fin.t = t; fin.aux = 0;
             fin.flags = (init.flags & LANE_F_OK);
-            stopped = true; done = true;
+            done = true;
           }
         }
       }
@@ -777,7 +772,7 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
       if ((at_stop || (eot_now && MODE != MODE_DOC && p >= stop_pos)) && !done) {
         fin.p = p; fin.t = t; fin.aux = 0;
         fin.flags = (F & 3u) | (init.flags & LANE_F_OK);
-        stopped = true; done = true;
+        done = true;
       }
       if (it > cap && !done) { st |= ST_STEP_LIMIT; done = true; }
     }
@@ -785,7 +780,7 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
   }
 #undef DTK_EOF_DRAIN
 
-  if (!stopped && !(st & (ST_STEP_LIMIT | ST_BAD_MODEL))) {
+  if (fin.p == 0xFFFFFFFFu && !(st & (ST_STEP_LIMIT | ST_BAD_MODEL))) {
     if (hi - bs > DTK_WINDOW && count_runes(s, bs, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
     if (MODE != MODE_START) {
       if (p > tp) {  // matrix.go:671-678
