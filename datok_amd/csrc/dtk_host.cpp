@@ -695,7 +695,6 @@ struct dtk_batch {
   uint8_t *d_evA = nullptr, *d_evB = nullptr;  // closing / opening event bytes (carved per run)
   uint8_t *d_acc = nullptr;                    // per-document accumulators + totals (one memset)
   uint64_t acc_bytes = 0;
-  uint32_t *d_tlen = nullptr;                  // token lengths at their end positions
   uint32_t *d_status = nullptr;
   // speculative chunk lanes
   std::vector<uint64_t> h_doc_off;   // host copy of the document offsets (lane planning)
@@ -796,7 +795,6 @@ extern "C" int dtk_batch_create(uint64_t max_bytes, uint32_t max_docs, dtk_batch
   B_TRY(hipMalloc((void **)&b->d_ev, 2 * (max_bytes + 4ull * max_docs + pad)));
   b->acc_bytes = 64 + 3 * ((uint64_t)max_docs + 1) * 8 + 3 * (uint64_t)max_docs * 4 + 64;
   B_TRY(hipMalloc((void **)&b->d_acc, b->acc_bytes));
-  B_TRY(hipMalloc((void **)&b->d_tlen, (max_bytes + 4ull * max_docs + pad) * 4));
   B_TRY(hipMalloc((void **)&b->d_redo, (uint64_t)max_docs * 4));
   B_TRY(hipMalloc((void **)&b->d_blk_doc, (max_bytes / DTK_SYM_BLOCK_BYTES + 3) * 4));
 
@@ -820,7 +818,7 @@ extern "C" int dtk_batch_create(uint64_t max_bytes, uint32_t max_docs, dtk_batch
 extern "C" void dtk_batch_free(dtk_batch *b) {
   if (!b) return;
   if (b->stream) (void)hipStreamSynchronize(b->stream);
-  void *ptrs[] = {b->d_text_own, b->d_off_own, b->d_sym, b->d_ev, b->d_acc, b->d_tlen, b->d_redo, b->d_chunk_off, b->d_blk_doc,
+  void *ptrs[] = {b->d_text_own, b->d_off_own, b->d_sym, b->d_ev, b->d_acc, b->d_redo, b->d_chunk_off, b->d_blk_doc,
                   b->d_lane_doc, b->d_lane_cnt, b->d_lane_start, b->d_lane_end, b->d_lane_plan,
                   b->d_tok_off,
                   b->d_sent_off, b->d_text_off, b->d_rstart, b->d_rend, b->d_sent,
@@ -961,7 +959,7 @@ static int plan_lanes(dtk_batch *b) {
 static DtkWalkArgs walk_args(dtk_batch *b) {
   DtkWalkArgs w{};
   w.sym = b->d_sym; w.doc_off = b->d_off; w.n_docs = b->n_docs;
-  w.evA = b->d_evA; w.evB = b->d_evB; w.tlen = b->d_tlen; w.status = b->d_status;
+  w.evA = b->d_evA; w.evB = b->d_evB; w.status = b->d_status;
   w.tok_cnt = b->d_tok_cnt; w.sent_cnt = b->d_sent_cnt; w.text_cnt = b->d_text_cnt;
   w.steps = (unsigned long long *)(b->d_totals + 4);
   w.step_factor = 2048;  // look-ahead is bounded by the 1024-rune window (matrix.go:365)
@@ -1047,7 +1045,7 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
   }
   DtkCompactArgs c{};
   c.text = b->d_text; c.sym = b->d_sym; c.doc_off = b->d_off; c.n_docs = b->n_docs;
-  c.evA = b->d_evA; c.evB = b->d_evB; c.tlen = b->d_tlen; c.status = b->d_status;
+  c.evA = b->d_evA; c.evB = b->d_evB; c.status = b->d_status;
   c.flags = flags & DTK_NEWLINE_AFTER_EOT; c.kind = m->kind;
   c.tok_off = b->d_tok_off; c.sent_off = b->d_sent_off; c.text_off = b->d_text_off;
   c.totals = b->d_totals;

@@ -32,7 +32,7 @@
 #define EV_S_EPS2 0x10u
 #define EV_S_EOF 0x20u
 #define EV_E_EOF 0x40u
-// 0x80 unused (token starts are derived from the token-length array)
+#define EV_TOK_START 0x80u  // opening byte of the position where the token starts (stored when it ends)
 #define EV_SMASK (EV_S_EOT | EV_S_EPS | EV_S_EPS2 | EV_S_EOF)
 #define EV_EMASK (EV_E_EOT | EV_E_EOF)
 
@@ -129,7 +129,6 @@ struct DtkWalkArgs {
   const uint64_t *doc_off;  // n_docs + 1
   uint32_t n_docs;
   uint8_t *evA, *evB;       // closing / opening event bytes, zero-filled; index DTK_EV_BASE + p
-  uint32_t *tlen;           // token byte length | rune length << 16, at the token's end position
   uint32_t *status;         // per document, OR-ed
   uint64_t *tok_cnt, *sent_cnt, *text_cnt;  // per document: what the writer would have collected
   unsigned long long *steps;  // global lookup counter
@@ -142,7 +141,6 @@ struct DtkCompactArgs {
   const uint64_t *doc_off;
   uint32_t n_docs;
   const uint8_t *evA, *evB;
-  const uint32_t *tlen;
   uint32_t *status;
   uint32_t flags;           // DTK_NEWLINE_AFTER_EOT
   int kind;                 // matrix / double array (EOT rewind rule differs)

@@ -330,9 +330,10 @@ struct DaTrans {
 // "closing" calls (S_EOT, E_EOT, TOK_END: what a rewind of the window fires) and
 // "opening" calls (the SentenceEnd / TextEnd fired afterwards), so that the lane
 // whose walk ends with a rewind at position q and the lane that starts from q
-// never store to the same byte.  A token is recorded at its END position only:
-// the closing byte plus (byte length | rune length << 16) in a third array, from
-// which the compaction derives its start.  Cursor positions of successive events
+// never store to the same byte.  A token is recorded by a TOK_END bit in the
+// closing byte of its end position and a TOK_START bit in the opening byte of its
+// start position (starts and ends alternate, so the compaction pairs them up and
+// gets byte and rune lengths from the positions).  Cursor positions of successive events
 // never decrease for the matrix walk, and no byte is written twice except in the
 // cases tracked here in registers (a second epsilon SentenceEnd at one cursor;
 // for the double array a token that ends where an EOT fired, datok.go:1019-1030
@@ -342,7 +343,6 @@ struct DaTrans {
 // remembered, the check pass then knows the lane left its window.
 struct EventSink {
   uint8_t *evA, *evB;  // closing / opening, index = position in the document
-  uint32_t *tlen;      // token lengths, index = end position
   uint32_t lo, hi;     // window
   uint32_t last_s_p, s_bits;      // position / byte of the last opening SentenceEnd
   uint32_t last_eot_p, eot_bits;  // position / byte of the last EOT pair (double array merge)
@@ -351,8 +351,8 @@ struct EventSink {
   // what NewTokenWriter would have collected from this lane's calls
   // (token_writer.go:72-81, 104-109, 131-159): tokens, ints of the sentence list, texts
   uint32_t c_tok, c_sent, c_text;
-  __device__ __forceinline__ void init(uint8_t *a, uint8_t *b, uint32_t *tl, uint32_t wlo, uint32_t whi) {
-    evA = a; evB = b; tlen = tl; lo = wlo; hi = whi;
+  __device__ __forceinline__ void init(uint8_t *a, uint8_t *b, uint32_t wlo, uint32_t whi) {
+    evA = a; evB = b; lo = wlo; hi = whi;
     last_s_p = last_eot_p = 0xFFFFFFFFu; s_bits = eot_bits = 0; st = 0; dropped = 0;
     c_tok = c_sent = c_text = 0;
   }
@@ -362,15 +362,16 @@ struct EventSink {
   // Token(bufft, buffer[:buffc]) -- matrix.go:528,569,675
   // sent_first: no token since the last SentenceEnd / TextEnd (the writer's sentB)
   template <bool IS_MATRIX>
-  __device__ __forceinline__ void token(uint32_t tp, uint32_t p, uint32_t rl, bool sent_first) {
+  __device__ __forceinline__ void token(uint32_t tp, uint32_t p, bool sent_first) {
     if (!in_closing(p)) { dropped = 1; return; }
     c_tok++;
     c_sent += sent_first ? 1u : 0u;
     uint32_t bits = EV_TOK_END;
     if (!IS_MATRIX && p == last_eot_p) bits |= eot_bits;
     evA[p] = (uint8_t)bits;
-    const uint32_t bl = p - tp;
-    tlen[p] = (bl > 0xFFFFu ? 0xFFFFu : bl) | ((rl > 0xFFFFu ? 0xFFFFu : rl) << 16);
+    // the start: behind the last rewind (this lane's window) and the skipped runes; a SentenceEnd
+    // may have fired at the same cursor before (same byte, stored by this lane)
+    evB[tp] = (uint8_t)(EV_TOK_START | (tp == last_s_p ? s_bits : 0u));
   }
   // SentenceEnd? + TextEnd fired by an EOT rune -- matrix.go:593-600
   // has_tok: the current text has a token (else the reference panics in position modes)
@@ -451,13 +452,12 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
   uint32_t t = init.t, aux = init.aux;  // matrix.go:351 `t := uint32(1)`
   const uint32_t t_start = tr.start_state(), aux_start = tr.start_aux();
   bool ok = (init.flags & LANE_F_OK) != 0;  // sticky `ok` of matrix.go:352 / datok.go:785
-  uint32_t eps_t = 0, eps_aux = 0, eps_p = 0, eps_rl = 0;  // epsilonState / epsilonOffset
+  uint32_t eps_t = 0, eps_aux = 0, eps_p = 0;  // epsilonState / epsilonOffset
   bool sentence_end = (init.flags & LANE_F_SENT) != 0, text_end = (init.flags & LANE_F_TEXT) != 0;
   uint32_t p = init.p;   // buffer[buffc]
   uint32_t tp = init.p;  // buffer[bufft]
   uint32_t bs = init.p;  // buffer[0]: position of the last rewind
   uint32_t hi = init.p;  // behind buffer[buffi-1]: read high-water mark
-  uint32_t rl = 0;       // runes in [tp, p)
   uint32_t w = 1;        // width of the rune at p
   bool eot = false, newchar = true;
   uint32_t st = 0, my_steps = 0;
@@ -484,7 +484,7 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
       const bool he = tr.has_eps(t, aux);          // goto PARSECHARM with a = epsilon
       const bool bt = !he && eps_t != 0;           // or pop the remembered epsilon state
       t0 = bt ? eps_t : t; aux0 = bt ? eps_aux : aux;
-      p = bt ? eps_p : p; rl = bt ? eps_rl : rl;
+      p = bt ? eps_p : p;
       eps_t = bt ? 0u : eps_t;
       a = epsilon;
       newchar = false;
@@ -508,7 +508,7 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
       t0 = t; aux0 = aux;              // matrix.go:437
       const bool he = tr.has_eps(t0, aux0);  // matrix.go:442-454
       eps_t = he ? t0 : eps_t; eps_aux = he ? aux0 : eps_aux;
-      eps_p = he ? p : eps_p; eps_rl = he ? rl : eps_rl;
+      eps_p = he ? p : eps_p;
     }
 
     bool nontoken = false;
@@ -541,7 +541,7 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
     if (hardfail || my_steps > cap) {  // rare
       if (hardfail) {  // drop what is buffered as a token, restart at state 1
         if (is_eps) { st |= ST_BAD_MODEL; done = true; hardfail = false; }  // stale-buffer case
-        else if (p <= tp) { p += w; rl++; }                                  // matrix.go:515-516
+        else if (p <= tp) { p += w; }                                        // matrix.go:515-516
         t = t_start; aux = aux_start;                                        // matrix.go:548
       }
       if (my_steps > cap) { st |= ST_STEP_LIMIT; done = true; hardfail = false; }
@@ -550,7 +550,7 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
     const bool flush = flush_eps || hardfail || flush_c;
     if (MODE != MODE_START) {
       if (flush)  // matrix.go:528 / 569
-        sink.template token<IS_MATRIX>(tp, p, rl, sentence_end || text_end || !any_tok);
+        sink.template token<IS_MATRIX>(tp, p, sentence_end || text_end || !any_tok);
       if (sent_eps || sent_c) sink.sentence(p, has_tok);  // matrix.go:575
     }
     any_tok = any_tok || flush;
@@ -560,7 +560,6 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
     const bool skip = (advance && p == tp && nontoken) || (comp && nontoken);  // matrix.go:584-588
     const uint32_t p_old = p;
     p = (advance || comp) ? p + w : p;
-    rl = skip ? 0u : (comp ? 1u : (advance ? rl + 1u : rl));
     tp = skip ? p : (comp ? p_old : tp);
     // the EOT fires a SentenceEnd unless one is pending (after the epsilon half of a fused cell)
     const bool eot_sent = !(flush_c ? false : (sent_c ? true : sentence_end));
@@ -568,7 +567,7 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
     text_end = eot_now ? true : (flush ? false : text_end);
     // retries keep the rune, everything else fetches a new one
     t0 = backtrack ? eps_t : t0; aux0 = backtrack ? eps_aux : aux0;
-    p = backtrack ? eps_p : p; rl = backtrack ? eps_rl : rl;
+    p = backtrack ? eps_p : p;
     a = backtrack ? epsilon : (retry_unknown ? unknown : a);
     eot = retry_unknown ? false : eot;  // matrix.go:555: a retry forgets that the rune was EOT
     newchar = succ || hardfail || comp;
@@ -577,7 +576,7 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
     if (TRANS::FUSED) {
       // the epsilon target is the state the rune was read in: remembered if it has an epsilon arc
       const bool he2 = comp && !(IS_MATRIX && eot_now) && tr.has_eps(via, 0u);
-      eps_t = he2 ? via : eps_t; eps_p = he2 ? p_old : eps_p; eps_rl = he2 ? 0u : eps_rl;
+      eps_t = he2 ? via : eps_t; eps_p = he2 ? p_old : eps_p;
     }
     // rare: EOT calls, the reference's 1024-rune window limit (checked where the window was
     // longest), end of this lane's chunk
@@ -601,14 +600,13 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
     }
     tp = rewind_end ? p : tp;  // matrix.go:537-543 / 608-627
     bs = rewind_end ? p : (flush_c ? p_old : bs);
-    rl = rewind_end ? 0u : rl;
   } while (!done);
 
   if (!stopped && !(st & (ST_STEP_LIMIT | ST_BAD_MODEL))) {
     if (hi - bs > DTK_WINDOW && count_runes(s, bs, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
     if (MODE != MODE_START) {
       if (p > tp) {  // matrix.go:671-678
-        sink.template token<IS_MATRIX>(tp, p, rl, sentence_end || text_end || !any_tok);
+        sink.template token<IS_MATRIX>(tp, p, sentence_end || text_end || !any_tok);
         sentence_end = false; text_end = false;
         has_tok = true;
       }
@@ -634,8 +632,8 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
   const uint32_t *__restrict__ tab = tr.tab;
   const uint32_t stride = tr.stride, n_eps = tr.n_eps;
   uint32_t t = init.t;
-  uint32_t p = init.p, tp = init.p, bs = init.p, hi = init.p, rl = 0;
-  uint32_t eps_t = 0, eps_p = 0, eps_rl = 0;
+  uint32_t p = init.p, tp = init.p, bs = init.p, hi = init.p;
+  uint32_t eps_t = 0, eps_p = 0;
   // F: 1 sentenceEnd, 2 textEnd (matrix.go:360-363), 4 some Token call happened in this document,
   //    8 the current text has a token (what NewTokenWriter's sentB / pos need)
   uint32_t F = (init.flags & (LANE_F_SENT | LANE_F_TEXT)) | (init.p > 0 ? 4u : 0u);
@@ -663,7 +661,7 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
     const bool he_ = t <= n_eps;                                     \
     const bool bt_ = !he_ && eps_t != 0;                             \
     t = bt_ ? eps_t : t;                                             \
-    p = bt_ ? eps_p : p; rl = bt_ ? eps_rl : rl;                     \
+    p = bt_ ? eps_p : p;                                             \
     eps_t = bt_ ? 0u : eps_t;                                        \
     retry = 1;                                                       \
     done = !he_ && !bt_;                                             \
@@ -701,7 +699,7 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
     }
     hi = max(hi, pn);                                   // matrix.go:388-408
     const bool he = !r && t <= n_eps;                   // matrix.go:442-454
-    eps_t = he ? t : eps_t; eps_p = he ? p : eps_p; eps_rl = he ? rl : eps_rl;
+    eps_t = he ? t : eps_t; eps_p = he ? p : eps_p;
     const uint32_t tgt = x & 0x7FFFu;
     const bool nontoken = (x & 0x8000u) != 0;
     const bool comp = (int32_t)x < 0 && (MODE == MODE_DOC || p < stop_pos);
@@ -714,7 +712,7 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
     const bool backtrack = fail && !r && eps_t != 0;    // matrix.go:487-497
     const bool hardfail = fail && !backtrack;
     if (MODE != MODE_START) {
-      if (flush) sink.template token<true>(tp, p, rl, ((F ^ 4u) & 7u) != 0);
+      if (flush) sink.template token<true>(tp, p, ((F ^ 4u) & 7u) != 0);
       if (sentE) sink.sentence(p, (F & 8u) != 0);
     }
     const uint32_t bs_old = bs;
@@ -723,19 +721,17 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
     const bool rewE = flush && !comp;                   // the rewind of a plain epsilon step ends a chunk
     const uint32_t p_old = p;
     p = (advance || comp) ? pn : p;
-    rl = skip ? 0u : (comp ? 1u : (advance ? rl + 1u : rl));
     tp = skip ? p : (comp ? p_old : tp);
     tp = rewE ? p : tp;
-    rl = rewE ? 0u : rl;
     bs = flush ? p_old : bs;
     // the epsilon slot: dropped by a backtrack, a rewind and a fused cell; a fused cell remembers
     // the state it read its rune in if that state has an epsilon arc
     const uint32_t via = (x >> 16) & 0x7FFFu;
     const bool he2 = comp && via <= n_eps;
     t = backtrack ? eps_t : ((plain || comp) ? tgt : t);
-    p = backtrack ? eps_p : p; rl = backtrack ? eps_rl : rl;
+    p = backtrack ? eps_p : p;
     eps_t = (backtrack || flush || comp) ? (he2 ? via : 0u) : eps_t;
-    eps_p = he2 ? p_old : eps_p; eps_rl = he2 ? 0u : eps_rl;
+    eps_p = he2 ? p_old : eps_p;
     retry = backtrack ? 1u : 0u;
     // everything that happens less than once per token
     const bool eot_now = (advance || comp) && ((e >> DTK_SYM_CLS_SHIFT) & 3u) == 1u;  // matrix.go:593-605
@@ -745,15 +741,15 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
       if (hardfail) {  // matrix.go:499-552: drop what is buffered as a token, restart at state 1
         if (r) { st |= ST_BAD_MODEL; done = true; }
         else {
-          if (p <= tp) { p = pn; rl++; }  // matrix.go:515-516
+          if (p <= tp) { p = pn; }  // matrix.go:515-516
           else {  // the rune is read again: its group, now
             grp = (p + o3) >> 2; q_cur = sq[grp]; q_next = sq[grp + 1u]; pend = 0;
           }
-          if (MODE != MODE_START) sink.template token<true>(tp, p, rl, ((F ^ 4u) & 7u) != 0);
+          if (MODE != MODE_START) sink.template token<true>(tp, p, ((F ^ 4u) & 7u) != 0);
           F = 12u;
           if (hi - bs > DTK_WINDOW && count_runes(s, bs, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
           t = tr.start; eps_t = 0;
-          tp = p; bs = p; rl = 0;
+          tp = p; bs = p;
           if (MODE != MODE_DOC && p >= stop_pos) {
             fin.p = p; fin.t = t; fin.aux = 0;
             fin.flags = (init.flags & LANE_F_OK);
@@ -767,7 +763,7 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
         F = (F & 4u) | 3u;  // sentenceEnd, textEnd; TextEnd: pos = pos[:0] (token_writer.go:158)
         eps_t = 0;          // matrix.go:601 rewinds
         if (hi - bs > DTK_WINDOW && count_runes(s, bs, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
-        tp = p; bs = p; rl = 0;
+        tp = p; bs = p;
       }
       if ((at_stop || (eot_now && MODE != MODE_DOC && p >= stop_pos)) && !done) {
         fin.p = p; fin.t = t; fin.aux = 0;
@@ -784,7 +780,7 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
     if (hi - bs > DTK_WINDOW && count_runes(s, bs, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
     if (MODE != MODE_START) {
       if (p > tp) {  // matrix.go:671-678
-        sink.template token<true>(tp, p, rl, ((F ^ 4u) & 7u) != 0);
+        sink.template token<true>(tp, p, ((F ^ 4u) & 7u) != 0);
         F = (F & ~3u) | 8u;
       }
       sink.tail(p, (F & 1u) != 0, (F & 2u) != 0, (F & 8u) != 0);  // matrix.go:683-691
@@ -833,7 +829,7 @@ __global__ __launch_bounds__(WAVE) void k_walk_doc(TRANS tr, DtkWalkArgs A, uint
     const uint32_t len = (uint32_t)(A.doc_off[d + 1] - off);
     EventSink sink;
     const uint64_t evb = DTK_EV_BASE(off, d);
-    sink.init(A.evA + evb, A.evB + evb, A.tlen + evb, 0u, 0xFFFFFFFFu);
+    sink.init(A.evA + evb, A.evB + evb, 0u, 0xFFFFFFFFu);
     DtkLaneState init{0u, tr.start_state(), tr.start_aux(), 0u}, fin;
     uint32_t st;
     walk_any<TRANS, IS_MATRIX, MODE_DOC>(tr, A.sym, off, len, init, 0u, sink, epsilon, unknown,
@@ -881,7 +877,7 @@ __global__ __launch_bounds__(WAVE) void k_spec_start(TRANS tr, DtkWalkArgs A, Dt
           while (sp < len && !(s[sp] & DTK_SYM_START)) sp++;
           DtkLaneState init{sp, tr.start_state(), tr.start_aux(), 0u};
           EventSink sink;
-          sink.init(nullptr, nullptr, nullptr, 0u, 0u);
+          sink.init(nullptr, nullptr, 0u, 0u);
           uint32_t st;
           walk_any<TRANS, IS_MATRIX, MODE_START>(tr, A.sym, off, len, init, kc, sink, epsilon, unknown,
                                                   identity, step_cap(A.step_factor, len), rec, st, steps);
@@ -889,7 +885,7 @@ __global__ __launch_bounds__(WAVE) void k_spec_start(TRANS tr, DtkWalkArgs A, Dt
         // sp == 0: the walk from the true initial state; its first sync point at/after kc
         else {
           EventSink sink;
-          sink.init(nullptr, nullptr, nullptr, 0u, 0u);
+          sink.init(nullptr, nullptr, 0u, 0u);
           uint32_t st;
           walk_any<TRANS, IS_MATRIX, MODE_START>(tr, A.sym, off, len, rec, kc, sink, epsilon, unknown,
                                                   identity, step_cap(A.step_factor, len), rec, st, steps);
@@ -1000,7 +996,7 @@ __global__ __launch_bounds__(WAVE) void k_spec_walk(TRANS tr, DtkWalkArgs A, Dtk
         const DtkLaneState init = S.lane_start[L];
         EventSink sink;
         const uint64_t evb = DTK_EV_BASE(off, d);
-        sink.init(A.evA + evb, A.evB + evb, A.tlen + evb, init.p, pl.wend);
+        sink.init(A.evA + evb, A.evB + evb, init.p, pl.wend);
         uint32_t st = 0;
         walk_any<TRANS, IS_MATRIX, MODE_CHUNK>(tr, A.sym, off, len, init, pl.stop, sink, epsilon, unknown,
                                                 identity, step_cap(A.step_factor, len), fin, st, steps);
@@ -1162,7 +1158,6 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
   const uint64_t evb = DTK_EV_BASE(off, d);
   const uint8_t *__restrict__ evA = A.evA + evb;
   const uint8_t *__restrict__ evB = A.evB + evb;
-  const uint32_t *__restrict__ tlen = A.tlen + evb;
   const uint16_t *__restrict__ sym = A.sym + off;
   const uint8_t *__restrict__ txt = A.text + off;
   const bool nl_rule = (A.flags & 16u) != 0;  // NEWLINE_AFTER_EOT
@@ -1183,6 +1178,7 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
   uint32_t cNSent = 0;       // sentence ints pushed before the round
   uint32_t cSEatEnd = 0, cEatEnd = 0;  // calls seen when the last token ended
   uint32_t cLastEndR = 0, cLastEndByte = 0;
+  uint32_t cStartP = 0, cStartR = 0;  // the last TOK_START seen: position, rune index
   int32_t cLastRend = 0;
   uint32_t cBase = 0;        // rune index that maps to offset 0 in the current text
   uint32_t cLastER = 0, cLastEByte = 0, cTokAtLastE = 0;
@@ -1287,8 +1283,14 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
     const uint32_t tokAtPrevE = haveE ? tokAtE_t : cTokAtLastE;
     const bool anyE = haveE || cHaveE;
 
-    // byte / rune length of the token that ends here (stored by the walk)
-    const uint32_t tl = isEnd ? tlen[P] : 0u;
+    // the token that ends here started at the last TOK_START strictly below this position
+    // (starts and ends alternate); byte and rune length follow from the two positions
+    const unsigned long long mSTART = __ballot(f & EV_TOK_START);
+    const unsigned long long mPrevStart = mSTART & lt;
+    const int js = mPrevStart ? highest(mPrevStart) : 0;
+    const uint32_t startP_t = __shfl(P, js), startR_t = __shfl(R, js);
+    const uint32_t startP = mPrevStart ? startP_t : cStartP;
+    const uint32_t startR = mPrevStart ? startR_t : cStartR;
     // rune index that counts as offset 0 for the text this token opens
     // (token_writer.go:66-81: posC restarts at 0; the offset handed to Token is
     // counted from the start of the window, which the matrix rewinds to the rune
@@ -1307,7 +1309,7 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
     const uint32_t baseFrom_t = __shfl(base_mine, jt);
     const uint32_t tbase = text_first ? base_mine : (mPrevTF ? baseFrom_t : cBase);
     const int32_t rend = (int32_t)(R - tbase);
-    const int32_t rstart = rend - (int32_t)(tl >> 16);
+    const int32_t rstart = rend - (int32_t)(R - startR);
 
     // end offset of the last token below this lane / at or below it
     const int32_t rendPrev_t = __shfl(rend, jp);
@@ -1329,7 +1331,7 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
 
     {
       if (isEnd && tok_base + k < tok_lim) {
-        A.tok_bstart[tok_base + k] = P - (tl & 0xFFFFu);
+        A.tok_bstart[tok_base + k] = startP;
         A.tok_bend[tok_base + k] = P;
         A.tok_rstart[tok_base + k] = rstart;
         A.tok_rend[tok_base + k] = rend;
@@ -1371,6 +1373,11 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
       cLastEndByte = __shfl(tb, jl);
       cLastRend = __shfl(rend, jl);
       cBase = __shfl(tbase, jl);
+    }
+    if (mSTART) {
+      const int jl = highest(mSTART);
+      cStartP = __shfl(P, jl);
+      cStartR = __shfl(R, jl);
     }
     if (mEEOT) {
       const int jl = highest(mEEOT);

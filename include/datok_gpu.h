@@ -204,7 +204,9 @@ enum {
   DTK_EV_S_EPS = 8,      /* SentenceEnd from an epsilon arc on an empty token (matrix.go:574-575) */
   DTK_EV_S_EPS2 = 16,    /* a second one at the same cursor */
   DTK_EV_S_EOF = 32,     /* final SentenceEnd (matrix.go:683-684) */
-  DTK_EV_E_EOF = 64      /* final TextEnd (matrix.go:690-691) */
+  DTK_EV_E_EOF = 64,     /* final TextEnd (matrix.go:690-691) */
+  DTK_EV_TOK_START = 128 /* events_open only: a token starts at this byte (bookkeeping of the device
+                            compaction; no call of the reference corresponds to it -- replays skip it) */
 };
 
 /* ---- NewTokenWriter(w, bits) (token_writer.go:36-175) for every document of the batch, rendered on
