@@ -691,6 +691,7 @@ struct dtk_batch {
   uint64_t total = 0;
   // intermediates
   uint16_t *d_sym = nullptr;
+  uint32_t *d_rsbits = nullptr;                // rune-start bitmap of the input (1 bit per byte)
   uint8_t *d_ev = nullptr;                     // both event arrays, cleared by one memset
   uint8_t *d_evA = nullptr, *d_evB = nullptr;  // closing / opening event bytes (carved per run)
   uint8_t *d_acc = nullptr;                    // per-document accumulators + totals (one memset)
@@ -792,6 +793,7 @@ extern "C" int dtk_batch_create(uint64_t max_bytes, uint32_t max_docs, dtk_batch
   B_TRY(hipMalloc((void **)&b->d_text_own, max_bytes + pad));
   B_TRY(hipMalloc((void **)&b->d_off_own, ((uint64_t)max_docs + 1) * 8));
   B_TRY(hipMalloc((void **)&b->d_sym, (max_bytes + pad) * 2));
+  B_TRY(hipMalloc((void **)&b->d_rsbits, (max_bytes + pad) / 8 + 64));
   B_TRY(hipMalloc((void **)&b->d_ev, 2 * (max_bytes + 4ull * max_docs + pad)));
   b->acc_bytes = 64 + 3 * ((uint64_t)max_docs + 1) * 8 + 3 * (uint64_t)max_docs * 4 + 64;
   B_TRY(hipMalloc((void **)&b->d_acc, b->acc_bytes));
@@ -818,7 +820,7 @@ extern "C" int dtk_batch_create(uint64_t max_bytes, uint32_t max_docs, dtk_batch
 extern "C" void dtk_batch_free(dtk_batch *b) {
   if (!b) return;
   if (b->stream) (void)hipStreamSynchronize(b->stream);
-  void *ptrs[] = {b->d_text_own, b->d_off_own, b->d_sym, b->d_ev, b->d_acc, b->d_redo, b->d_chunk_off, b->d_blk_doc,
+  void *ptrs[] = {b->d_text_own, b->d_off_own, b->d_sym, b->d_rsbits, b->d_ev, b->d_acc, b->d_redo, b->d_chunk_off, b->d_blk_doc,
                   b->d_lane_doc, b->d_lane_cnt, b->d_lane_start, b->d_lane_end, b->d_lane_plan,
                   b->d_tok_off,
                   b->d_sent_off, b->d_text_off, b->d_rstart, b->d_rend, b->d_sent,
@@ -1026,7 +1028,7 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
   }
   STAGE(1);
   if (dtk_launch_symbolize(b->d_text, b->d_off, b->n_docs, b->total, &m->sig, b->d_sym,
-                           b->d_text == b->d_text_own, b->d_blk_doc, (unsigned long long *)(b->d_totals + 6), s))
+                           b->d_text == b->d_text_own, b->d_blk_doc, (unsigned long long *)(b->d_totals + 6), b->d_rsbits, s))
     return hip_fail(hipGetLastError(), "symbolize");
   STAGE(2);
   DtkWalkArgs w = walk_args(b);
@@ -1044,7 +1046,7 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
     }
   }
   DtkCompactArgs c{};
-  c.text = b->d_text; c.sym = b->d_sym; c.doc_off = b->d_off; c.n_docs = b->n_docs;
+  c.text = b->d_text; c.rs_bits = b->d_rsbits; c.doc_off = b->d_off; c.n_docs = b->n_docs;
   c.evA = b->d_evA; c.evB = b->d_evB; c.status = b->d_status;
   c.flags = flags & DTK_NEWLINE_AFTER_EOT; c.kind = m->kind;
   c.tok_off = b->d_tok_off; c.sent_off = b->d_sent_off; c.text_off = b->d_text_off;

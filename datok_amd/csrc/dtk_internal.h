@@ -137,7 +137,7 @@ struct DtkWalkArgs {
 
 struct DtkCompactArgs {
   const uint8_t *text;
-  const uint16_t *sym;
+  const uint32_t *rs_bits;  // bit g: input byte g starts a rune (k_symbolize)
   const uint64_t *doc_off;
   uint32_t n_docs;
   const uint8_t *evA, *evB;
@@ -187,7 +187,8 @@ extern "C" {
 // launchers (dtk_kernels.hip); stream is a hipStream_t
 int dtk_launch_symbolize(const uint8_t *text, const uint64_t *doc_off, uint32_t n_docs,
                          uint64_t total, const struct DtkSigmaDev *sig, uint16_t *sym, int padded,
-                         const uint32_t *blk_doc, unsigned long long *n_invalid, void *stream);
+                         const uint32_t *blk_doc, unsigned long long *n_invalid, uint32_t *rs_bits,
+                         void *stream);
 #define DTK_SYM_BLOCK_BYTES 4096u  // input bytes per symbolise block (blk_doc granularity)
 int dtk_launch_walk(const struct DtkTableDev *tab, const struct DtkWalkArgs *args, void *stream);
 int dtk_launch_spec(const struct DtkTableDev *tab, const struct DtkWalkArgs *args,

@@ -89,7 +89,9 @@ __global__ __launch_bounds__(WAVE) void k_symbolize(const uint8_t *__restrict__ 
                                                     uint32_t n_docs, uint64_t total, DtkSigmaDev sig,
                                                     uint16_t *__restrict__ sym,
                                                     const uint32_t *__restrict__ blk_doc,
-                                                    unsigned long long *__restrict__ n_invalid) {
+                                                    unsigned long long *__restrict__ n_invalid,
+                                                    uint32_t *__restrict__ rs_bits) {
+  __shared__ uint32_t s_rs[SYM_BLOCK_BYTES / 32];  // bit i: byte i of the block starts a rune
   __shared__ uint16_t lut[128];       // symbol | class | START for the runes < 128 (index = byte)
   __shared__ uint16_t lat[256];       // symbol | class for runes < 256 (heavy path, Latin-1)
   __shared__ uint32_t s_runes[256];   // sigma map (runes >= 256)
@@ -98,6 +100,7 @@ __global__ __launch_bounds__(WAVE) void k_symbolize(const uint8_t *__restrict__ 
   __shared__ uint16_t s_q[SYM_HALF];  // positions (offset in the block) of the bytes >= 0x80 of one half
   const uint32_t lane = threadIdx.x;
   const bool sig_lds = sig.n_runes <= 256u;
+  for (uint32_t i = lane; i < SYM_BLOCK_BYTES / 32; i += WAVE) s_rs[i] = 0;
   for (uint32_t i = lane; i < 256u; i += WAVE) {
     // matrix.go:421-426: runes < 256 go through sigmaASCII; rune 4 is EOT
     const uint32_t e = (sig.ascii[i] & DTK_SYM_MASK) | (i == DTK_EOT ? (1u << DTK_SYM_CLS_SHIFT) : 0u);
@@ -157,7 +160,14 @@ __global__ __launch_bounds__(WAVE) void k_symbolize(const uint8_t *__restrict__ 
         const uint32_t o[4] = {e0, e1, e2, e3};
         for (uint32_t j = 0; j < left; j++) sym[block_start + i0 + j] = (uint16_t)o[j];
       }
-      const uint32_t hib = (w & 0x80808080u) & (left >= 4u ? 0xFFFFFFFFu : ((1u << (8u * left)) - 1u));
+      const uint32_t live = left >= 4u ? 0xFFFFFFFFu : ((1u << (8u * left)) - 1u);
+      const uint32_t hib = (w & 0x80808080u) & live;
+      {
+        // bytes < 0x80 start a rune; the others are decided one by one below
+        const uint32_t asc = (~w & 0x80808080u) & live;
+        const uint32_t nib = ((asc >> 7) & 1u) | ((asc >> 14) & 2u) | ((asc >> 21) & 4u) | ((asc >> 28) & 8u);
+        if (nib) atomicOr(&s_rs[i0 >> 5], nib << (i0 & 31u));
+      }
       if (__ballot(hib != 0u) != 0ull) {
         const uint32_t rare = ((hib >> 7) & 1u) | ((hib >> 14) & 2u) | ((hib >> 21) & 4u) | ((hib >> 28) & 8u);
         uint32_t tot;
@@ -232,12 +242,18 @@ __global__ __launch_bounds__(WAVE) void k_symbolize(const uint8_t *__restrict__ 
           }
         }
         sym[g] = (uint16_t)(a_cls | ((wd - 1) << DTK_SYM_W_SHIFT) | (start ? DTK_SYM_START : 0u));
+        if (start) atomicOr(&s_rs[pos >> 5], 1u << (pos & 31u));
         // a byte that decodes to U+FFFD with width 1 prints as three bytes (the renderer's slow path)
         if (start && wd == 1u) atomicAdd(n_invalid, 1ull);
       }
     }
     __syncthreads();  // the queue is reused by the next half
   }
+  // the block's rune-start bitmap (bit g of the array = input byte g): the compaction counts
+  // runes with it instead of reading the symbol stream again
+  __syncthreads();
+  for (uint32_t i = lane; i < SYM_BLOCK_BYTES / 32; i += WAVE)
+    if (i * 32u < n_here) rs_bits[(block_start >> 5) + i] = s_rs[i];
 }
 
 // --------------------------------------------------------------------- walk
@@ -1158,7 +1174,6 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
   const uint64_t evb = DTK_EV_BASE(off, d);
   const uint8_t *__restrict__ evA = A.evA + evb;
   const uint8_t *__restrict__ evB = A.evB + evb;
-  const uint16_t *__restrict__ sym = A.sym + off;
   const uint8_t *__restrict__ txt = A.text + off;
   const bool nl_rule = (A.flags & 16u) != 0;  // NEWLINE_AFTER_EOT
   const bool is_matrix = A.kind == DTK_KIND_MATRIX;
@@ -1197,9 +1212,12 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
       fw = *reinterpret_cast<const uint32_t *>(evA + P0) | *reinterpret_cast<const uint32_t *>(evB + P0);
       const uint32_t left = n_pos - P0;  // positions of mine that exist
       if (left < 4u) fw &= (1u << (8u * left)) - 1u;
-#pragma unroll
-      for (int j = 0; j < 4; j++)
-        if (P0 + j < len) rsn |= (uint32_t)(sym[P0 + j] >> 15) << j;
+      // rune starts of my 4 positions from the bitmap (bit = input byte index)
+      const uint64_t g0 = off + P0;
+      const uint32_t *wp = A.rs_bits + (g0 >> 5);
+      const uint64_t two = (uint64_t)wp[0] | ((uint64_t)wp[1] << 32);
+      const uint32_t have = len > P0 ? (len - P0 >= 4u ? 4u : len - P0) : 0u;
+      rsn = (uint32_t)(two >> (g0 & 31u)) & ((1u << have) - 1u);
     }
     const uint32_t evn = ((fw & 0xFFu) ? 1u : 0u) | ((fw & 0xFF00u) ? 2u : 0u) | ((fw & 0xFF0000u) ? 4u : 0u) |
                          ((fw & 0xFF000000u) ? 8u : 0u);
@@ -1229,7 +1247,8 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
     if (lane < take) {
       const uint32_t at = (qhead + lane) & (CQ_CAP - 1u);
       P = qpos[at]; f = qfl[at]; R = qrn[at];
-      if ((f & (EV_TOK_END | EV_E_EOT)) && P < len) tb = txt[P];  // byte behind a token / an EOT
+      // byte behind a token / an EOT: only the NEWLINE_AFTER_EOT rule looks at it (token_writer.go:66-68)
+      if (nl_rule && (f & (EV_TOK_END | EV_E_EOT)) && P < len) tb = txt[P];
     }
     qhead += take;
     qn -= take;
@@ -1451,17 +1470,18 @@ __global__ __launch_bounds__(1024) void k_scan3(const uint64_t *ca, const uint64
 
 extern "C" int dtk_launch_symbolize(const uint8_t *text, const uint64_t *doc_off, uint32_t n_docs,
                                     uint64_t total, const DtkSigmaDev *sig, uint16_t *sym, int padded,
-                                    const uint32_t *blk_doc, unsigned long long *n_invalid, void *stream) {
+                                    const uint32_t *blk_doc, unsigned long long *n_invalid, uint32_t *rs_bits,
+                                    void *stream) {
   if (total == 0 || n_docs == 0) return 0;
   const uint32_t blocks = (uint32_t)((total + SYM_BLOCK_BYTES - 1) / SYM_BLOCK_BYTES);
   // ALIGNED4 may read up to 3 bytes past `total`: true for the batch's own (padded) buffer;
   // a caller-owned device buffer only qualifies when its size is a multiple of 4
   if ((((uintptr_t)text) & 3u) == 0 && (padded || (total & 3u) == 0))
     hipLaunchKernelGGL(k_symbolize<true>, dim3(blocks), dim3(WAVE), 0, (hipStream_t)stream, text, doc_off, n_docs,
-                       total, *sig, sym, blk_doc, n_invalid);
+                       total, *sig, sym, blk_doc, n_invalid, rs_bits);
   else
     hipLaunchKernelGGL(k_symbolize<false>, dim3(blocks), dim3(WAVE), 0, (hipStream_t)stream, text, doc_off, n_docs,
-                       total, *sig, sym, blk_doc, n_invalid);
+                       total, *sig, sym, blk_doc, n_invalid, rs_bits);
   return (int)hipGetLastError();
 }
 
