@@ -988,7 +988,9 @@ static int launch_compact2(dtk_batch *b) {
   a.tok_rstart = b->d_rstart; a.tok_rend = b->d_rend;
   a.tok_bstart = b->d_bstart; a.tok_bend = b->d_bend;
   a.sent = b->d_sent; a.text_tok_end = b->d_ttok; a.text_sent_end = b->d_tsent;
-  a.tok_sbefore = b->d_sbefore; a.text_s_end = b->d_ts_end; a.doc_ns = b->d_doc_ns;
+  const bool ro = (b->last_flags & DTK_OFFSETS_ONLY) != 0;  // no renderer bookkeeping
+  a.tok_sbefore = ro ? nullptr : b->d_sbefore; a.text_s_end = ro ? nullptr : b->d_ts_end;
+  a.doc_ns = ro ? nullptr : b->d_doc_ns;
   a.tok_cap = b->tok_cap; a.sent_cap = b->sent_cap; a.text_cap = b->text_cap;
   b->last_args = a;
   if (dtk_launch_compact(&a, 2, b->stream)) return hip_fail(hipGetLastError(), "compact pass 2");
@@ -1212,6 +1214,7 @@ static int render(dtk_batch *b, uint32_t bits) {
   int rc = finish(b);
   if (rc != DTK_OK) return rc;
   if (bits & ~31u) return DTK_E_ARG;
+  if (b->last_flags & DTK_OFFSETS_ONLY) return DTK_E_STATE;  // the run skipped the renderer's bookkeeping
   // the positions were computed under the run's NEWLINE_AFTER_EOT rule (token_writer.go:66-68)
   if ((bits ^ b->last_flags) & DTK_NEWLINE_AFTER_EOT) return DTK_E_ARG;
   bits &= 15u;

@@ -1354,7 +1354,7 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
         A.tok_bend[tok_base + k] = P;
         A.tok_rstart[tok_base + k] = rstart;
         A.tok_rend[tok_base + k] = rend;
-        A.tok_sbefore[tok_base + k] = sBeforeEnd;  // SentenceEnd calls before this Token call
+        if (A.tok_sbefore) A.tok_sbefore[tok_base + k] = sBeforeEnd;  // SentenceEnd calls before this Token call
       }
       uint64_t si = sent_base + cNSent + excl;
       if (si + c <= sent_lim) {
@@ -1369,7 +1369,7 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
         if (ti < text_lim) {
           A.text_tok_end[ti] = te;
           A.text_sent_end[ti] = cNSent + excl + s1_valid;
-          A.text_s_end[ti] = sBeforeEnd;  // SentenceEnd calls before this TextEnd call
+          if (A.text_s_end) A.text_s_end[ti] = sBeforeEnd;  // SentenceEnd calls before this TextEnd call
         } else status |= ST_INTERNAL;
       }
       if (f & EV_E_EOF) {
@@ -1377,7 +1377,7 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
         if (ti < text_lim) {
           A.text_tok_end[ti] = tokLate;
           A.text_sent_end[ti] = cNSent + excl + c;
-          A.text_s_end[ti] = sBeforeEnd + sLate;
+          if (A.text_s_end) A.text_s_end[ti] = sBeforeEnd + sLate;
         } else status |= ST_INTERNAL;
       }
       if (isEnd && tok_base + k >= tok_lim) status |= ST_INTERNAL;
@@ -1423,7 +1423,7 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
       sred |= ST_INTERNAL;
     sred &= ST_INTERNAL;  // everything else was reported by the walk already
     if (sred) atomicOr(&A.status[d], sred);
-    A.doc_ns[d] = cNSev;  // SentenceEnd calls of this document (for rendering)
+    if (A.doc_ns) A.doc_ns[d] = cNSev;  // SentenceEnd calls of this document (for rendering)
   }
 }
 

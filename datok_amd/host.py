@@ -11,6 +11,7 @@ from ._lib import ModelInfo, RenderView, ResultView, Totals, check, lib
 # token_writer.go:17-25
 TOKENS, SENTENCES, TOKEN_POS, SENTENCE_POS, NEWLINE_AFTER_EOT = 1, 2, 4, 8, 16
 SIMPLE = TOKENS | SENTENCES
+OFFSETS_ONLY = 256   # Batch.run only: skip the device renderer's bookkeeping
 
 EV_S_EOT, EV_E_EOT, EV_TOK_END, EV_S_EPS, EV_S_EPS2, EV_S_EOF, EV_E_EOF = 1, 2, 4, 8, 16, 32, 64
 

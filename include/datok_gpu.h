@@ -47,7 +47,10 @@ enum {
   DTK_TOKEN_POS = 4,
   DTK_SENTENCE_POS = 8,
   DTK_NEWLINE_AFTER_EOT = 16,
-  DTK_SIMPLE = 3
+  DTK_SIMPLE = 3,
+  /* dtk_batch_run only (not a reference bit): the caller wants the offset arrays only; the
+   * per-token bookkeeping of dtk_batch_render_* is not written (a render then returns DTK_E_STATE) */
+  DTK_OFFSETS_ONLY = 256
 };
 
 /* ---- per-document status bits: inputs on which the reference panics or
@@ -127,7 +130,8 @@ int dtk_batch_set_chunking(dtk_batch *b, uint32_t chunk_bytes, uint32_t warm_byt
 
 /* Launches the whole path on the batch's stream (asynchronous):
  * symbolise -> walk -> count -> scan -> compact.  flags: DTK_NEWLINE_AFTER_EOT
- * is the only bit that changes the numbers (token_writer.go:66-68). */
+ * is the only bit that changes the numbers (token_writer.go:66-68); DTK_OFFSETS_ONLY
+ * skips what only the device renderer needs. */
 int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags);
 int dtk_batch_sync(dtk_batch *b);
 void *dtk_batch_stream(dtk_batch *b); /* hipStream_t, for event timing by the caller */

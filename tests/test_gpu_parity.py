@@ -295,6 +295,14 @@ def test_device_rendering_config2(gpu, oracle_models, model):
                 assert est == 0 and data[int(o[d]):int(o[d + 1])] == exp, (bits, d)
         with pytest.raises(datok_amd.DatokGpuError):
             b.render(SIMPLE | NEWLINE_AFTER_EOT)   # positions were computed without that rule
+        # offsets only (what bench.py runs): same arrays, no renderer bookkeeping
+        full = b.result()
+        b.run(gpu(model), datok_amd.host.OFFSETS_ONLY)
+        lean = b.result()
+        for f in ("tok_off", "tok_rstart", "tok_rend", "tok_bstart", "tok_bend", "sent", "text_tok_end", "status"):
+            assert np.array_equal(getattr(full, f), getattr(lean, f)), f
+        with pytest.raises(datok_amd.DatokGpuError):
+            b.render(SIMPLE)
 
 
 def test_device_rendering_single_long_stream(gpu, oracle_models):
