@@ -240,7 +240,8 @@ def main():
                        "batches_in_flight": len(batches)},
             "roofline": {"bound": "hbm",
                          "kernel": ("k_spec_walk<%s, true>" if tot["chunk_bytes"] else "k_walk_doc<%s, true>") % (
-                             "MatrixFusedTrans" if tok.info["entry_bytes"] == 4 and tok.info["state_count"] < 32767
+                             ("MatrixLeanTrans" if not tok.info["unknown_used"] else "MatrixFusedTrans")
+                             if tok.info["entry_bytes"] == 4 and tok.info["state_count"] < 32767
                              else "MatrixTrans<u%d>" % (8 * tok.info["entry_bytes"])),
                          "achieved": round(achieved, 2),
                          "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 6),

@@ -155,7 +155,11 @@ __global__ __launch_bounds__(WAVE) void k_symbolize(const uint8_t *__restrict__ 
       const uint32_t e2 = lut[(w >> 16) & 0x7Fu], e3 = lut[(w >> 24) & 0x7Fu];
       const uint32_t left = i0 < n_here ? (n_here - i0 >= 4u ? 4u : n_here - i0) : 0u;
       if (left == 4u && sym8) {
+#ifndef DTK_EXP_NO_SYMW
         *reinterpret_cast<uint2 *>(sym + block_start + i0) = make_uint2(e0 | (e1 << 16), e2 | (e3 << 16));
+#else
+        if (e0 == 0x12345u) *reinterpret_cast<uint2 *>(sym + block_start + i0) = make_uint2(e0 | (e1 << 16), e2 | (e3 << 16));
+#endif
       } else {
         const uint32_t o[4] = {e0, e1, e2, e3};
         for (uint32_t j = 0; j < left; j++) sym[block_start + i0 + j] = (uint16_t)o[j];
@@ -267,6 +271,7 @@ struct MatrixTrans {
   uint32_t stride, n_eps, start;
   static constexpr CELL FLAG = (CELL)((CELL)1 << (sizeof(CELL) * 8 - 1));
   static constexpr bool FUSED = false;
+  static constexpr bool LEAN = false;
   __device__ __forceinline__ uint32_t start_state() const { return start; }
   __device__ __forceinline__ uint32_t start_aux() const { return 0; }
   // matrix.go:442 `array[(epsilon-1)*stateCount+t0] != 0` after renumbering
@@ -293,8 +298,8 @@ struct MatrixFusedTrans {
   const uint32_t *tab;
   uint32_t stride, n_eps, start;
   uint32_t ident_guard;  // the identity symbol if the model has arcs on `unknown`, else no symbol
-  uint32_t plain_walk;   // 1: use the general loop even where the lean one applies (A/B, tests)
   static constexpr bool FUSED = true;
+  static constexpr bool LEAN = false;
   __device__ __forceinline__ uint32_t start_state() const { return start; }
   __device__ __forceinline__ uint32_t start_aux() const { return 0; }
   __device__ __forceinline__ bool has_eps(uint32_t t, uint32_t) const { return t <= n_eps; }
@@ -311,10 +316,17 @@ struct MatrixFusedTrans {
   }
 };
 
+// The same table walked by the lean loop (walk_fused): chosen by the launcher when no state has an
+// arc on `unknown` (a separate type so that the kernels only carry one loop: fewer registers).
+struct MatrixLeanTrans : MatrixFusedTrans {
+  static constexpr bool LEAN = true;
+};
+
 struct DaTrans {
   const uint2 *arr;  // .x base (bit31 separate, bit30 has-epsilon cache), .y check
   uint32_t len, size, base1;
   static constexpr bool FUSED = false;
+  static constexpr bool LEAN = false;
   __device__ __forceinline__ uint32_t start_state() const { return 1u; }  // datok.go:784
   __device__ __forceinline__ uint32_t start_aux() const { return base1; }
   // datok.go:876, precomputed per index at load
@@ -806,20 +818,17 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
   steps_out = it;  // lookups
 }
 
-// the lean walk applies: fused cells and no arc on `unknown` (ident_guard is then "no symbol")
+// the lean walk: fused cells and no arc on `unknown` (MatrixLeanTrans, picked by the launcher)
 template <typename TRANS, bool IS_MATRIX, int MODE>
 __device__ __forceinline__ void walk_any(const TRANS &tr, const uint16_t *__restrict__ sym_base, uint64_t off,
                                          uint32_t len, DtkLaneState init, uint32_t stop_pos, EventSink &sink,
                                          uint32_t epsilon, uint32_t unknown, uint32_t identity, uint32_t cap,
                                          DtkLaneState &fin, uint32_t &st_out, uint32_t &steps_out) {
-  if constexpr (TRANS::FUSED) {
-    if (tr.ident_guard == 0xFFFFFFFFu && !tr.plain_walk) {
-      walk_fused<MODE>(tr, sym_base, off, len, init, stop_pos, sink, epsilon, cap, fin, st_out, steps_out);
-      return;
-    }
-  }
-  walk_lane<TRANS, IS_MATRIX, MODE>(tr, sym_base, off, len, init, stop_pos, sink, epsilon, unknown, identity, cap,
-                                    fin, st_out, steps_out);
+  if constexpr (TRANS::LEAN)
+    walk_fused<MODE>(tr, sym_base, off, len, init, stop_pos, sink, epsilon, cap, fin, st_out, steps_out);
+  else
+    walk_lane<TRANS, IS_MATRIX, MODE>(tr, sym_base, off, len, init, stop_pos, sink, epsilon, unknown, identity, cap,
+                                      fin, st_out, steps_out);
 }
 
 __device__ __forceinline__ uint32_t step_cap(uint32_t factor, uint32_t len) {
@@ -1489,9 +1498,14 @@ template <typename F>
 static int with_trans(const DtkTableDev *tab, F &&f) {
   if (tab->kind == DTK_KIND_MATRIX) {
     if (tab->fused) {
-      MatrixFusedTrans tr{(const uint32_t *)tab->tab, tab->stride, tab->n_eps, tab->start, tab->ident_guard,
-                          tab->plain_walk};
-      f(tr, std::true_type{});
+      MatrixFusedTrans tr{(const uint32_t *)tab->tab, tab->stride, tab->n_eps, tab->start, tab->ident_guard};
+      if (tab->ident_guard == 0xFFFFFFFFu && !tab->plain_walk) {  // the lean loop applies
+        MatrixLeanTrans lt;
+        static_cast<MatrixFusedTrans &>(lt) = tr;
+        f(lt, std::true_type{});
+      } else {
+        f(tr, std::true_type{});
+      }
     } else if (tab->entry_bytes == 2) {
       MatrixTrans<uint16_t> tr{(const uint16_t *)tab->tab, tab->stride, tab->n_eps, tab->start};
       f(tr, std::true_type{});
