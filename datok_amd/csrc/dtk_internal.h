@@ -32,7 +32,9 @@
 #define EV_S_EPS2 0x10u
 #define EV_S_EOF 0x20u
 #define EV_E_EOF 0x40u
-#define EV_TOK_START 0x80u  // opening byte of the position where the token starts (stored when it ends)
+#define EV_TOK_START 0x80u  // opening byte of the position where a token of >= EV_LEN_LONG bytes starts
+#define EV_LEN_SHIFT 3      // closing byte, bits 3-7: byte length of the token that ends here, or EV_LEN_LONG
+#define EV_LEN_LONG 31u
 #define EV_SMASK (EV_S_EOT | EV_S_EPS | EV_S_EPS2 | EV_S_EOF)
 #define EV_EMASK (EV_E_EOT | EV_E_EOF)
 

@@ -359,9 +359,10 @@ struct DaTrans {
 // "opening" calls (the SentenceEnd / TextEnd fired afterwards), so that the lane
 // whose walk ends with a rewind at position q and the lane that starts from q
 // never store to the same byte.  A token is recorded by a TOK_END bit in the
-// closing byte of its end position and a TOK_START bit in the opening byte of its
-// start position (starts and ends alternate, so the compaction pairs them up and
-// gets byte and rune lengths from the positions).  Cursor positions of successive events
+// closing byte of its end position, with its byte length in the upper five bits of
+// that byte; a token of 31 bytes or more (length field saturated) also sets a
+// TOK_START bit in the opening byte of its start position, and the compaction pairs
+// such starts and ends up.  Rune lengths come from the rune-start bitmap.  Cursor positions of successive events
 // never decrease for the matrix walk, and no byte is written twice except in the
 // cases tracked here in registers (a second epsilon SentenceEnd at one cursor;
 // for the double array a token that ends where an EOT fired, datok.go:1019-1030
@@ -396,10 +397,14 @@ struct EventSink {
     c_sent += sent_first ? 1u : 0u;
     uint32_t bits = EV_TOK_END;
     if (!IS_MATRIX && p == last_eot_p) bits |= eot_bits;
-    evA[p] = (uint8_t)bits;
-    // the start: behind the last rewind (this lane's window) and the skipped runes; a SentenceEnd
-    // may have fired at the same cursor before (same byte, stored by this lane)
-    evB[tp] = (uint8_t)(EV_TOK_START | (tp == last_s_p ? s_bits : 0u));
+    // the byte length rides in the upper five bits of the closing byte; a token of 31 bytes or
+    // more additionally marks its start in the opening byte of its first position (a SentenceEnd
+    // may have fired at that cursor before: same byte, stored by this lane)
+    const uint32_t bl = p - tp;
+#ifndef DTK_EXP_NO_EVA
+    evA[p] = (uint8_t)(bits | ((bl < EV_LEN_LONG ? bl : EV_LEN_LONG) << EV_LEN_SHIFT));
+#endif
+    if (bl >= EV_LEN_LONG) evB[tp] = (uint8_t)(EV_TOK_START | (tp == last_s_p ? s_bits : 0u));
   }
   // SentenceEnd? + TextEnd fired by an EOT rune -- matrix.go:593-600
   // has_tok: the current text has a token (else the reference panics in position modes)
@@ -1214,11 +1219,13 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
   for (uint32_t base = 0; base < n_pos; base += 4u * WAVE) {
     // ---- light phase
     const uint32_t P0 = base + lane * 4u;
-    uint32_t fw = 0, rsn = 0;  // 4 event bytes (one per position), rune-start nibble
+    uint32_t fw = 0, lw = 0, rsn = 0;  // 4 event bytes (one per position), token length fields, rune-start nibble
     if (P0 < n_pos) {
       // DTK_EV_BASE is 4-byte aligned and the arrays are padded: whole dwords are readable,
       // bytes behind position `len` are zero (cleared, never written)
-      fw = *reinterpret_cast<const uint32_t *>(evA + P0) | *reinterpret_cast<const uint32_t *>(evB + P0);
+      const uint32_t fa = *reinterpret_cast<const uint32_t *>(evA + P0);
+      fw = (fa & 0x07070707u) | *reinterpret_cast<const uint32_t *>(evB + P0);
+      lw = (fa >> EV_LEN_SHIFT) & 0x1F1F1F1Fu;
       const uint32_t left = n_pos - P0;  // positions of mine that exist
       if (left < 4u) fw &= (1u << (8u * left)) - 1u;
       // rune starts of my 4 positions from the bitmap (bit = input byte index)
@@ -1239,7 +1246,7 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
       if (evn & (1u << j)) {
         const uint32_t at = slot & (CQ_CAP - 1u);
         qpos[at] = P0 + j;
-        qfl[at] = (fw >> (8 * j)) & 0xFFu;
+        qfl[at] = ((fw >> (8 * j)) & 0xFFu) | (((lw >> (8 * j)) & 0x1Fu) << 8);
         qrn[at] = Rl + (uint32_t)__popc(rsn & ((1u << j) - 1u));
         slot++;
       }
@@ -1311,14 +1318,23 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
     const uint32_t tokAtPrevE = haveE ? tokAtE_t : cTokAtLastE;
     const bool anyE = haveE || cHaveE;
 
-    // the token that ends here started at the last TOK_START strictly below this position
-    // (starts and ends alternate); byte and rune length follow from the two positions
+    // where the token that ends here started: its length field, or -- saturated field -- the last
+    // TOK_START strictly below this position (long tokens' starts and ends alternate); the rune
+    // length is the number of rune starts in between (bitmap for the short ones)
+    const uint32_t lenf = (f >> 8) & 0x1Fu;
     const unsigned long long mSTART = __ballot(f & EV_TOK_START);
     const unsigned long long mPrevStart = mSTART & lt;
     const int js = mPrevStart ? highest(mPrevStart) : 0;
     const uint32_t startP_t = __shfl(P, js), startR_t = __shfl(R, js);
-    const uint32_t startP = mPrevStart ? startP_t : cStartP;
-    const uint32_t startR = mPrevStart ? startR_t : cStartR;
+    uint32_t startP = mPrevStart ? startP_t : cStartP;
+    uint32_t startR = mPrevStart ? startR_t : cStartR;
+    if (isEnd && lenf < EV_LEN_LONG) {
+      startP = P - lenf;
+      const uint64_t g = off + startP;
+      const uint32_t *wp = A.rs_bits + (g >> 5);
+      const uint64_t two = (uint64_t)wp[0] | ((uint64_t)wp[1] << 32);
+      startR = R - (uint32_t)__popcll((two >> (g & 31u)) & ((1ull << lenf) - 1ull));
+    }
     // rune index that counts as offset 0 for the text this token opens
     // (token_writer.go:66-81: posC restarts at 0; the offset handed to Token is
     // counted from the start of the window, which the matrix rewinds to the rune

@@ -367,7 +367,8 @@ class Batch:
         r.text_sent_end = arr(v.text_sent_end, t["n_texts"], np.uint32)
         r.status = arr(v.status, nd, np.uint32)
         n_ev = self.total + 4 * nd + 4
-        r.events = arr(v.events, n_ev, np.uint8) | arr(v.events_open, n_ev, np.uint8)
+        # closing events are the low three bits of `events` (the rest is a length field of the device compaction)
+        r.events = (arr(v.events, n_ev, np.uint8) & np.uint8(7)) | arr(v.events_open, n_ev, np.uint8)
         r.doc_off = self._doc_off
         return r
 

@@ -114,7 +114,7 @@ inline void replay(bool is_matrix, const uint8_t *text, size_t n, const uint8_t 
   size_t k = 0;      // tokens replayed so far (index into tok_bstart)
   std::vector<rune> buf;
   for (size_t p = 0; p <= n; p++) {
-    const uint8_t e = (uint8_t)(ev_close[p] | ev_open[p]);
+    const uint8_t e = (uint8_t)((ev_close[p] & DTK_EV_CLOSE_MASK) | ev_open[p]);
     if (!e) continue;
     auto buffc = [&]() { return count_runes(text + B, p - B); };
     if (e & DTK_EV_S_EOT) w.SentenceEnd(buffc());

@@ -184,9 +184,11 @@ typedef struct {
   const uint32_t *status;
   /* raw walk output, for replay into TokenWriter closures: one byte per byte
    * position p = 0..len of every document, at index DTK_EVENT_BASE(doc_off[d], d) + p.  The calls
-   * fired by a window rewind (S_EOT, E_EOT, TOK_END) are in `events`, all
-   * others in `events_open`; OR the two bytes.  The k-th TOK_END of a document
-   * belongs to its k-th token (tok_bstart/tok_bend). */
+   * fired by a window rewind (S_EOT, E_EOT, TOK_END) are in the low three bits of `events`, all
+   * others in `events_open`: (events[i] & DTK_EV_CLOSE_MASK) | events_open[i] is the event byte.
+   * The k-th TOK_END of a document belongs to its k-th token (tok_bstart/tok_bend).  The upper
+   * five bits of `events` carry the token's byte length (31: 31 or more, then DTK_EV_TOK_START
+   * marks its first byte in events_open) -- bookkeeping of the device compaction. */
   const uint8_t *events;
   const uint8_t *events_open;
 } dtk_result_view;
@@ -209,8 +211,9 @@ enum {
   DTK_EV_S_EPS2 = 16,    /* a second one at the same cursor */
   DTK_EV_S_EOF = 32,     /* final SentenceEnd (matrix.go:683-684) */
   DTK_EV_E_EOF = 64,     /* final TextEnd (matrix.go:690-691) */
-  DTK_EV_TOK_START = 128 /* events_open only: a token starts at this byte (bookkeeping of the device
-                            compaction; no call of the reference corresponds to it -- replays skip it) */
+  DTK_EV_TOK_START = 128,/* events_open only: a token of >= 31 bytes starts at this byte (bookkeeping of the
+                            device compaction; no call of the reference corresponds to it -- replays skip it) */
+  DTK_EV_CLOSE_MASK = 7  /* the event bits of `events` (its upper bits are a length field) */
 };
 
 /* ---- NewTokenWriter(w, bits) (token_writer.go:36-175) for every document of the batch, rendered on
