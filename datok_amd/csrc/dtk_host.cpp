@@ -715,6 +715,7 @@ struct dtk_batch {
   uint32_t last_flags = 0;
   uint64_t *d_tok_off = nullptr, *d_sent_off = nullptr, *d_text_off = nullptr;
   uint64_t *d_tok_cnt = nullptr, *d_sent_cnt = nullptr, *d_text_cnt = nullptr;  // per-document counts
+  uint64_t *d_scan_ws = nullptr;  // tile sums of the multi-block scan (many documents)
   uint64_t *d_totals = nullptr;  // [0..3] scan totals, [4] walk steps, [5] documents to repair (u32), [6] invalid UTF-8 bytes
   uint64_t *h_totals = nullptr;  // pinned
   // outputs (grown on demand, never inside a run unless a re-launch is needed)
@@ -805,6 +806,7 @@ extern "C" int dtk_batch_create(uint64_t max_bytes, uint32_t max_docs, dtk_batch
   B_TRY(hipMalloc((void **)&b->d_sent_off, ((uint64_t)max_docs + 1) * 8));
   B_TRY(hipMalloc((void **)&b->d_text_off, ((uint64_t)max_docs + 1) * 8));
   B_TRY(hipMalloc((void **)&b->d_doc_ns, ((uint64_t)max_docs + 1) * 4));
+  B_TRY(hipMalloc((void **)&b->d_scan_ws, ((uint64_t)max_docs / 2048 + 2) * 4 * 8));
   B_TRY(hipMalloc((void **)&b->d_out_off, ((uint64_t)max_docs + 1) * 8));
 
   B_TRY(hipHostMalloc((void **)&b->h_totals, 8 * 8, hipHostMallocDefault));
@@ -825,7 +827,7 @@ extern "C" void dtk_batch_free(dtk_batch *b) {
                   b->d_tok_off,
                   b->d_sent_off, b->d_text_off, b->d_rstart, b->d_rend, b->d_sent,
                   b->d_bstart, b->d_bend, b->d_ttok, b->d_tsent,
-                  b->d_sbefore, b->d_ts_end, b->d_doc_ns, b->d_rws, b->d_out_off, b->d_out};
+                  b->d_sbefore, b->d_ts_end, b->d_doc_ns, b->d_scan_ws, b->d_rws, b->d_out_off, b->d_out};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (b->h_totals) (void)hipHostFree(b->h_totals);
@@ -1057,7 +1059,7 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
   c.totals = b->d_totals;
   // rows are sized by the walk's own counts (no counting pass)
   if (dtk_launch_scan3(b->d_tok_cnt, b->d_sent_cnt, b->d_text_cnt, b->d_tok_off, b->d_sent_off, b->d_text_off,
-                       b->n_docs, b->d_totals, b->d_status, s))
+                       b->n_docs, b->d_totals, b->d_status, b->d_scan_ws, s))
     return hip_fail(hipGetLastError(), "scan");
   STAGE(8);
   b->last_args = c;
@@ -1120,7 +1122,7 @@ static int finish(dtk_batch *b) {
       if (b->repair_rounds > 1000000u) return DTK_E_STATE;
     }
     if (dtk_launch_scan3(b->d_tok_cnt, b->d_sent_cnt, b->d_text_cnt, b->d_tok_off, b->d_sent_off, b->d_text_off,
-                       b->n_docs, b->d_totals, b->d_status, s))
+                       b->n_docs, b->d_totals, b->d_status, b->d_scan_ws, s))
       return hip_fail(hipGetLastError(), "scan");
     int rc = launch_compact2(b);
     if (rc != DTK_OK) return rc;

@@ -200,7 +200,8 @@ int dtk_launch_compact(const struct DtkCompactArgs *args, int pass, void *stream
 int dtk_launch_render(const struct DtkRenderArgs *args, int stage, void *stream);
 uint32_t dtk_render_tiles(uint64_t n);
 int dtk_launch_scan3(const uint64_t *ca, const uint64_t *cb, const uint64_t *cc, uint64_t *a, uint64_t *b,
-                     uint64_t *c, uint32_t n_docs, uint64_t *totals, const uint32_t *status, void *stream);
+                     uint64_t *c, uint32_t n_docs, uint64_t *totals, const uint32_t *status, uint64_t *ws,
+                     void *stream);
 #ifdef __cplusplus
 }
 #endif

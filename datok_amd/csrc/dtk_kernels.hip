@@ -1375,8 +1375,10 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
 
     {
       if (isEnd && tok_base + k < tok_lim) {
+#ifndef DTK_EXP_NO_BSTORE
         A.tok_bstart[tok_base + k] = startP;
         A.tok_bend[tok_base + k] = P;
+#endif
         A.tok_rstart[tok_base + k] = rstart;
         A.tok_rend[tok_base + k] = rend;
         if (A.tok_sbefore) A.tok_sbefore[tok_base + k] = sBeforeEnd;  // SentenceEnd calls before this Token call
@@ -1600,10 +1602,91 @@ extern "C" int dtk_launch_compact(const DtkCompactArgs *args, int pass, void *st
   return (int)hipGetLastError();
 }
 
+// Many documents: the same scan in three launches (tile sums, scan of the sums, tiles).
+#define SCAN_TB 256u
+#define SCAN_PER 8u
+#define SCAN_TILE (SCAN_TB * SCAN_PER)
+
+__device__ __forceinline__ uint64_t scan_block_excl(uint64_t v, uint64_t *sh, uint64_t &total) {
+  const uint32_t tid = threadIdx.x;
+  sh[tid] = v;
+  __syncthreads();
+  for (uint32_t o = 1; o < SCAN_TB; o <<= 1) {
+    const uint64_t x = tid >= o ? sh[tid - o] : 0;
+    __syncthreads();
+    sh[tid] += x;
+    __syncthreads();
+  }
+  total = sh[SCAN_TB - 1];
+  const uint64_t ex = sh[tid] - v;
+  __syncthreads();
+  return ex;
+}
+
+__global__ __launch_bounds__(SCAN_TB) void k_scan3_sums(const uint64_t *ca, const uint64_t *cb, const uint64_t *cc,
+                                                        const uint32_t *status, uint32_t n, uint64_t *ws) {
+  __shared__ uint64_t sh[SCAN_TB];
+  const uint32_t i0 = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER;
+  uint64_t s[4] = {0, 0, 0, 0};
+  for (uint32_t i = i0; i < i0 + SCAN_PER && i < n; i++) { s[0] += ca[i]; s[1] += cb[i]; s[2] += cc[i]; s[3] += status[i] != 0; }
+  for (int j = 0; j < 4; j++) {
+    uint64_t tot;
+    (void)scan_block_excl(s[j], sh, tot);
+    if (threadIdx.x == 0) ws[4u * blockIdx.x + j] = tot;
+  }
+}
+
+__global__ __launch_bounds__(SCAN_TB) void k_scan3_mid(uint64_t *ws, uint32_t nb, uint64_t *a, uint64_t *b, uint64_t *c,
+                                                       uint32_t n, uint64_t *totals) {
+  __shared__ uint64_t sh[SCAN_TB];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t per = (nb + SCAN_TB - 1) / SCAN_TB;
+  const uint32_t lo = min(tid * per, nb), hi = min(lo + per, nb);
+  for (int j = 0; j < 4; j++) {
+    uint64_t sm = 0;
+    for (uint32_t i = lo; i < hi; i++) sm += ws[4u * i + j];
+    uint64_t tot;
+    uint64_t run = scan_block_excl(sm, sh, tot);
+    for (uint32_t i = lo; i < hi; i++) { const uint64_t v = ws[4u * i + j]; ws[4u * i + j] = run; run += v; }
+    if (tid == 0) {
+      totals[j] = tot;
+      if (j == 0) a[n] = tot;
+      if (j == 1) b[n] = tot;
+      if (j == 2) c[n] = tot;
+    }
+  }
+}
+
+__global__ __launch_bounds__(SCAN_TB) void k_scan3_apply(const uint64_t *ca, const uint64_t *cb, const uint64_t *cc,
+                                                         uint64_t *a, uint64_t *b, uint64_t *c, uint32_t n,
+                                                         const uint64_t *ws) {
+  __shared__ uint64_t sh[SCAN_TB];
+  const uint32_t i0 = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER;
+  const uint64_t *src[3] = {ca, cb, cc};
+  uint64_t *dst[3] = {a, b, c};
+  for (int j = 0; j < 3; j++) {
+    uint64_t v[SCAN_PER], sm = 0;
+    for (uint32_t q = 0; q < SCAN_PER; q++) { v[q] = i0 + q < n ? src[j][i0 + q] : 0; sm += v[q]; }
+    uint64_t tot;
+    uint64_t run = ws[4u * blockIdx.x + j] + scan_block_excl(sm, sh, tot);
+    for (uint32_t q = 0; q < SCAN_PER; q++) {
+      if (i0 + q < n) dst[j][i0 + q] = run;
+      run += v[q];
+    }
+  }
+}
+
 extern "C" int dtk_launch_scan3(const uint64_t *ca, const uint64_t *cb, const uint64_t *cc, uint64_t *a,
                                 uint64_t *b, uint64_t *c, uint32_t n_docs, uint64_t *totals,
-                                const uint32_t *status, void *stream) {
-  hipLaunchKernelGGL(k_scan3, dim3(1), dim3(1024), 0, (hipStream_t)stream, ca, cb, cc, a, b, c, n_docs, totals,
-                     status);
+                                const uint32_t *status, uint64_t *ws, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (n_docs <= 8192u || !ws) {
+    hipLaunchKernelGGL(k_scan3, dim3(1), dim3(1024), 0, s, ca, cb, cc, a, b, c, n_docs, totals, status);
+  } else {
+    const uint32_t nb = (n_docs + SCAN_TILE - 1) / SCAN_TILE;
+    hipLaunchKernelGGL(k_scan3_sums, dim3(nb), dim3(SCAN_TB), 0, s, ca, cb, cc, status, n_docs, ws);
+    hipLaunchKernelGGL(k_scan3_mid, dim3(1), dim3(SCAN_TB), 0, s, ws, nb, a, b, c, n_docs, totals);
+    hipLaunchKernelGGL(k_scan3_apply, dim3(nb), dim3(SCAN_TB), 0, s, ca, cb, cc, a, b, c, n_docs, ws);
+  }
   return (int)hipGetLastError();
 }

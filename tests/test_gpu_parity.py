@@ -428,3 +428,24 @@ int main(int argc, char **argv) {
     assert a == simple and b == full
     nt, ns, ne = (int(x) for x in c.split())
     assert nt == simple.count(b"\n") - ns - ne and ne == 2 and ns >= 3
+
+
+def test_many_small_documents(gpu, oracle_models):
+    """20 000 documents of 10..200 bytes (the row offsets then come from the multi-block scan; lanes
+    are single chunks): every document against the oracle."""
+    from datok_amd import corpus
+    text, off = corpus.german_docs(512, 4096, seed=77)
+    raw = text.tobytes()
+    rng = np.random.default_rng(5)
+    cuts = [0]
+    while cuts[-1] < len(raw) and len(cuts) <= 20000:
+        nxt = min(len(raw), cuts[-1] + int(rng.integers(10, 200)))
+        while nxt < len(raw) and (raw[nxt] & 0xC0) == 0x80:   # keep the pieces valid UTF-8
+            nxt += 1
+        cuts.append(nxt)
+    cuts = np.array(cuts, dtype=np.uint64)
+    piece = np.frombuffer(raw[:int(cuts[-1])], dtype=np.uint8)
+    assert len(cuts) - 1 > 8192
+    res, tot = run_batch(gpu("tokenizer_de.matok"), piece, cuts)
+    assert tot["n_docs"] == len(cuts) - 1
+    assert assert_batch_equals_oracle(oracle_models("tokenizer_de.matok"), res, piece, cuts) > 8192
