@@ -80,7 +80,7 @@ __device__ __forceinline__ uint32_t doc_of(const uint64_t *__restrict__ doc_off,
 }
 
 #define SYM_BLOCK_BYTES DTK_SYM_BLOCK_BYTES
-#define SYM_TILE 256u
+#define SYM_TILE 512u
 #define SYM_HALF 2048u  // the heavy pass runs once per this many bytes
 
 template <bool ALIGNED4>
@@ -96,8 +96,9 @@ __global__ __launch_bounds__(WAVE) void k_symbolize(const uint8_t *__restrict__ 
   __shared__ uint16_t lat[256];       // symbol | class for runes < 256 (heavy path, Latin-1)
   __shared__ uint32_t s_runes[256];   // sigma map (runes >= 256)
   __shared__ uint16_t s_syms[256];
-  __shared__ uint32_t s_txt[SYM_BLOCK_BYTES / 4 + 2];  // the block's bytes, one dword of halo either side
+  __shared__ uint32_t s_txt[SYM_BLOCK_BYTES / 4 + 4];  // the block's bytes, one dword of halo either side
   __shared__ uint16_t s_q[SYM_HALF];  // positions (offset in the block) of the bytes >= 0x80 of one half
+  __shared__ uint32_t s_qn;           // entries queued
   const uint32_t lane = threadIdx.x;
   const bool sig_lds = sig.n_runes <= 256u;
   for (uint32_t i = lane; i < SYM_BLOCK_BYTES / 32; i += WAVE) s_rs[i] = 0;
@@ -138,52 +139,54 @@ __global__ __launch_bounds__(WAVE) void k_symbolize(const uint8_t *__restrict__ 
   const uint32_t d_lo = blk_doc[blockIdx.x];
   const uint32_t d_hi = min(blk_doc[blockIdx.x + 1], n_docs - 1);
   const uint64_t lo_start = doc_off[d_lo], lo_end = doc_off[d_lo + 1];  // the block's first document
-  const bool sym8 = ((reinterpret_cast<uintptr_t>(sym) + 2ull * block_start) & 7u) == 0;
+  const bool sym16 = ((reinterpret_cast<uintptr_t>(sym) + 2ull * block_start) & 15u) == 0;
 
 #pragma unroll 1
   for (uint32_t half = 0; half < SYM_BLOCK_BYTES / SYM_HALF; half++) {
     if (half * SYM_HALF >= n_here) break;
     // ---- light: every byte < 0x80 is a complete rune: its entry goes straight to memory
-    //      (8-byte stores); the positions of the other bytes are queued
-    uint32_t nq = 0;  // wave-uniform
+    //      (16-byte stores, 8 bytes of input per lane); the positions of the other bytes are queued
+    //      (slots from an LDS counter: the heavy pass does not care about their order)
+    if (lane == 0) s_qn = 0;
+    __syncthreads();
 #pragma unroll 1
     for (uint32_t it = 0; it < SYM_HALF / SYM_TILE; it++) {
-      const uint32_t i0 = half * SYM_HALF + it * SYM_TILE + lane * 4u;  // my 4 bytes (offset in the block)
+      const uint32_t i0 = half * SYM_HALF + it * SYM_TILE + lane * 8u;  // my 8 bytes (offset in the block)
       if (half * SYM_HALF + it * SYM_TILE >= n_here) break;
-      const uint32_t w = s_txt[1 + (i0 >> 2)];
-      const uint32_t e0 = lut[w & 0x7Fu], e1 = lut[(w >> 8) & 0x7Fu];
-      const uint32_t e2 = lut[(w >> 16) & 0x7Fu], e3 = lut[(w >> 24) & 0x7Fu];
-      const uint32_t left = i0 < n_here ? (n_here - i0 >= 4u ? 4u : n_here - i0) : 0u;
-      if (left == 4u && sym8) {
-#ifndef DTK_EXP_NO_SYMW
-        *reinterpret_cast<uint2 *>(sym + block_start + i0) = make_uint2(e0 | (e1 << 16), e2 | (e3 << 16));
-#else
-        if (e0 == 0x12345u) *reinterpret_cast<uint2 *>(sym + block_start + i0) = make_uint2(e0 | (e1 << 16), e2 | (e3 << 16));
-#endif
+      const uint32_t w0 = s_txt[1 + (i0 >> 2)], w1 = s_txt[2 + (i0 >> 2)];
+      const uint32_t e0 = lut[w0 & 0x7Fu], e1 = lut[(w0 >> 8) & 0x7Fu];
+      const uint32_t e2 = lut[(w0 >> 16) & 0x7Fu], e3 = lut[(w0 >> 24) & 0x7Fu];
+      const uint32_t e4 = lut[w1 & 0x7Fu], e5 = lut[(w1 >> 8) & 0x7Fu];
+      const uint32_t e6 = lut[(w1 >> 16) & 0x7Fu], e7 = lut[(w1 >> 24) & 0x7Fu];
+      const uint32_t left = i0 < n_here ? (n_here - i0 >= 8u ? 8u : n_here - i0) : 0u;
+      if (left == 8u && sym16) {
+        *reinterpret_cast<uint4 *>(sym + block_start + i0) =
+            make_uint4(e0 | (e1 << 16), e2 | (e3 << 16), e4 | (e5 << 16), e6 | (e7 << 16));
       } else {
-        const uint32_t o[4] = {e0, e1, e2, e3};
+        const uint32_t o[8] = {e0, e1, e2, e3, e4, e5, e6, e7};
         for (uint32_t j = 0; j < left; j++) sym[block_start + i0 + j] = (uint16_t)o[j];
       }
-      const uint32_t live = left >= 4u ? 0xFFFFFFFFu : ((1u << (8u * left)) - 1u);
-      const uint32_t hib = (w & 0x80808080u) & live;
-      {
-        // bytes < 0x80 start a rune; the others are decided one by one below
-        const uint32_t asc = (~w & 0x80808080u) & live;
-        const uint32_t nib = ((asc >> 7) & 1u) | ((asc >> 14) & 2u) | ((asc >> 21) & 4u) | ((asc >> 28) & 8u);
-        if (nib) atomicOr(&s_rs[i0 >> 5], nib << (i0 & 31u));
-      }
-      if (__ballot(hib != 0u) != 0ull) {
-        const uint32_t rare = ((hib >> 7) & 1u) | ((hib >> 14) & 2u) | ((hib >> 21) & 4u) | ((hib >> 28) & 8u);
-        uint32_t tot;
-        uint32_t slot = nq + wave_excl_scan((uint32_t)__popc(rare), tot);
+      // one bit per byte: bytes < 0x80 start a rune (the others are decided one by one below)
+      const uint32_t lo4 = left >= 4u ? 0xFFFFFFFFu : ((1u << (8u * left)) - 1u);
+      const uint32_t hi4 = left >= 8u ? 0xFFFFFFFFu : (left > 4u ? ((1u << (8u * (left - 4u))) - 1u) : 0u);
+      const uint32_t h0 = (w0 & 0x80808080u) & lo4, h1 = (w1 & 0x80808080u) & hi4;
+      const uint32_t a0 = (~w0 & 0x80808080u) & lo4, a1 = (~w1 & 0x80808080u) & hi4;
+      auto nib = [](uint32_t x) { return ((x >> 7) & 1u) | ((x >> 14) & 2u) | ((x >> 21) & 4u) | ((x >> 28) & 8u); };
+      const uint32_t asc = nib(a0) | (nib(a1) << 4);
+      if (asc) atomicOr(&s_rs[i0 >> 5], asc << (i0 & 31u));
+      const uint32_t rare = nib(h0) | (nib(h1) << 4);
+      if (rare) {
+        uint32_t slot = atomicAdd(&s_qn, (uint32_t)__popc(rare));
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int j = 0; j < 8; j++)
           if (rare & (1u << j)) s_q[slot++] = (uint16_t)(i0 + j);
-        nq += tot;
       }
     }
+    __syncthreads();
+    const uint32_t nq = s_qn;  // wave-uniform
     if (nq == 0) continue;
     // the heavy lanes overwrite single entries written above: those stores must have landed
+    // (staging the block's entries in LDS instead costs more in occupancy than this wait: measured)
     __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) lgkmcnt(0): stores count in vmcnt on gfx950
     __syncthreads();
 
