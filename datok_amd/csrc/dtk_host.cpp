@@ -977,6 +977,13 @@ static DtkSpecArgs spec_args(dtk_batch *b, bool redo) {
   s.lane_start = b->d_lane_start; s.lane_end = b->d_lane_end; s.lane_plan = b->d_lane_plan;
   s.lane_cnt = b->d_lane_cnt; s.first_bad = b->d_first_bad; s.fail_lane = b->d_fail_lane;
   s.redo_from = redo ? b->d_redo : nullptr;
+  s.text = b->d_text;
+  {
+    static const char *e = getenv("DATOK_WARM_WS");
+    s.warm_ws = e ? (uint32_t)atoi(e) : 0u;
+    static const char *e2 = getenv("DATOK_WARM_MIN");
+    s.warm_min = e2 ? (uint32_t)atoi(e2) : 0u;
+  }
   return s;
 }
 

@@ -124,6 +124,9 @@ struct DtkSpecArgs {
   uint32_t *first_bad;              // per document: first chunk without a linked successor
   uint32_t *fail_lane;              // per document: first lane that missed its successor's record
   const uint32_t *redo_from;        // repair rounds: first lane to redo per document, or null
+  const uint8_t *text;              // input bytes (k_spec_start: whitespace-guided warm-up), or null
+  uint32_t warm_ws;                 // start the warm-up behind the warm_ws-th whitespace run before the chunk (0: fixed)
+  uint32_t warm_min;                // ... looking backwards from chunk start - warm_min
 };
 
 struct DtkWalkArgs {

@@ -906,6 +906,24 @@ __global__ __launch_bounds__(WAVE) void k_spec_start(TRANS tr, DtkWalkArgs A, Dt
       if (k > 0) {
         const uint32_t kc = k * S.chunk;
         uint32_t sp = kc > S.warm ? kc - S.warm : 0u;
+        if (sp > 0 && S.warm_ws && S.text) {
+          // The walk re-synchronises at token boundaries, and blanks are boundaries in every
+          // tokenizer of this kind: start behind the warm_ws-th run of blanks before the chunk
+          // instead of a fixed distance (never further back than `warm`).  A wrong guess only
+          // costs a repair round.
+          const uint8_t *tx = S.text + off;
+          uint32_t runs = 0, q = kc > S.warm_min ? kc - S.warm_min : 0u;
+          if (q < sp) q = sp;
+          bool in_ws = false;
+          while (q > sp) {
+            const uint8_t c = tx[q - 1u];
+            const bool ws = c == ' ' || c == '\n' || c == '\t' || c == '\r';
+            if (in_ws && !ws) { if (++runs == S.warm_ws) break; }
+            in_ws = ws;
+            q--;
+          }
+          sp = q;  // first byte of the run of blanks (the walk skips them), or the fixed start
+        }
         if (sp > 0) {
           while (sp < len && !(s[sp] & DTK_SYM_START)) sp++;
           DtkLaneState init{sp, tr.start_state(), tr.start_aux(), 0u};
