@@ -167,7 +167,13 @@ def _edge_docs():
             "„Zitat“ – so … ‚x‘ »y« ∞ ≠ ≤ 日本語 テスト".encode(), "😀 emoji 👍🏽 ok".encode(),
             b"\xff\xfe invalid \x80\x80 bytes \xc3", b"\xe2\x82", b"\xf0\x9f\x98", b"ab\xc0\xafcd",
             b"x" * 1100, b" " * 1100 + b"x", b"a " * 700, ("ä" * 1030).encode(), b"." * 300,
-            "Der Vorsitzende der Abk. hat gewählt. Gefunden auf wikipedia.org.".encode()]
+            "Der Vorsitzende der Abk. hat gewählt. Gefunden auf wikipedia.org.".encode(),
+            # token length field of the closing event byte: 30 / 31 / 32 bytes and longer (start marks),
+            # also right behind a sentence end without a blank and as the first / last token
+            b"z" * 30, b"z" * 31, b"z" * 32, b"A." + b"x" * 40, b"Satz. " + b"q" * 31 + b" und " + b"q" * 30,
+            ("ä" * 15).encode(), ("ä" * 16).encode(), b"Hallo! " + b"w" * 64 + b" Ende.",
+            b"http://www.example.org/a/very/long/path/with/many/segments/index.html?x=1&y=2 ok",
+            b"k" * 31 + b"\x04" + b"m" * 33 + b"\x04\n" + b"n" * 31]
     alphabet = list(" \n\t.,;:!?'\"()-@/&%abcdefgABCDE0123äöüß„“»«…€") + ["\x04"]
     for _ in range(300):
         k = int(rng.integers(0, 200))
