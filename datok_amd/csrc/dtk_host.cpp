@@ -795,7 +795,8 @@ extern "C" int dtk_batch_create(uint64_t max_bytes, uint32_t max_docs, dtk_batch
   B_TRY(hipMalloc((void **)&b->d_off_own, ((uint64_t)max_docs + 1) * 8));
   B_TRY(hipMalloc((void **)&b->d_sym, (max_bytes + pad) * 2));
   B_TRY(hipMalloc((void **)&b->d_rsbits, (max_bytes + pad) / 8 + 64));
-  B_TRY(hipMalloc((void **)&b->d_ev, 2 * (max_bytes + 4ull * max_docs + pad)));
+  // per array: total + 4 * n_docs + 4 slots, rounded up to 256 by dtk_batch_run
+  B_TRY(hipMalloc((void **)&b->d_ev, 2 * (max_bytes + 4ull * max_docs + 2 * pad)));
   b->acc_bytes = 64 + 3 * ((uint64_t)max_docs + 1) * 8 + 3 * (uint64_t)max_docs * 4 + 64;
   B_TRY(hipMalloc((void **)&b->d_acc, b->acc_bytes));
   B_TRY(hipMalloc((void **)&b->d_redo, (uint64_t)max_docs * 4));

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Soak parity run: many seeds x corpora x walk configurations, every document of every batch
+against the oracle (bit exact).  Not part of pytest (minutes); run on an MI355X:
+    python scripts/soak.py [seeds] [first_seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import datok_amd  # noqa: E402
+from datok_amd import corpus  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+from parity import assert_batch_equals_oracle  # noqa: E402
+
+M = os.path.join(ROOT, "tests", "golden", "models")
+n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+
+ALPHA = list(" \n\t.,;:!?'\"()-@/&%abcdefgABCDE0123äöüß„“»«…€<>=") + ["\x04"]
+
+
+def random_docs(rng, n):
+    docs = []
+    for _ in range(n):
+        k = int(rng.integers(0, 600))
+        kind = rng.integers(0, 4)
+        if kind == 0:     # raw bytes, mostly invalid UTF-8
+            docs.append(bytes(rng.integers(0, 256, size=k, dtype=np.uint8)))
+        elif kind == 1:   # long tokens around the 31-byte length field
+            parts = []
+            while sum(map(len, parts)) < k:
+                parts.append("x" * int(rng.integers(1, 70)) + str(rng.choice([" ", ". ", "\n", ", ", "! ", " - "])))
+            docs.append("".join(parts).encode())
+        else:
+            docs.append("".join(ALPHA[int(i)] for i in rng.integers(0, len(ALPHA), size=k)).encode())
+    return corpus.concat_docs(docs)
+
+
+models = {name: (datok_amd.load_tokenizer_file(os.path.join(M, name)), O.Model(os.path.join(M, name)))
+          for name in ("tokenizer_de.matok", "tokenizer_en.matok", "tokenizer_de.datok", "clitic_test.matok")}
+t0 = time.time()
+total_docs = 0
+for seed in range(first, first + n_seeds):
+    rng = np.random.default_rng(seed)
+    cases = [("tokenizer_de.matok", corpus.german_docs(int(rng.integers(64, 600)), int(rng.choice([512, 4096, 9000])), seed=seed)),
+             ("tokenizer_en.matok", corpus.english_zipf_docs(int(rng.integers(64, 400)), seed=seed, max_bytes=16384)),
+             ("tokenizer_de.datok", corpus.german_docs(128, 4096, seed=seed + 7)),
+             (str(rng.choice(list(models))), random_docs(rng, 300))]
+    for name, (text, off) in cases:
+        tok, om = models[name]
+        chunk, warm = [(None, 48), (0, 48), (64, 48), (128, 16), (256, 48), (48, 0), (1024, 48)][int(rng.integers(0, 7))]
+        flags = int(rng.choice([0, 16]))
+        with datok_amd.Batch(max(len(text), 1), len(off) - 1) as b:
+            if chunk is not None:
+                b.set_chunking(chunk, warm)
+            b.set_input(text, off)
+            b.run(tok, flags)
+            res, tot = b.result(), b.totals()
+            irregular = {d for d in range(len(off) - 1) if res.status[d] & datok_amd.ST_IRREGULAR}
+            assert not irregular or name.endswith(".datok"), (seed, name)
+            keep = [d for d in range(len(off) - 1) if d not in irregular]
+            assert_batch_equals_oracle(om, res, text, off, flags, docs=keep)
+            # and the rendered SIMPLE stream of a sample
+            data, o = b.render(3 | flags)
+            raw = text.tobytes()
+            for d in keep[::max(1, len(keep) // 40)]:
+                exp, est = om.transduce(raw[int(off[d]):int(off[d + 1])], 3 | flags)
+                if est == 0 and not (int(res.status[d]) & ~datok_amd.ST_EMPTY_TEXT):
+                    assert data[int(o[d]):int(o[d + 1])] == exp, (seed, name, d)
+            total_docs += len(keep)
+    if (seed - first) % 5 == 4:
+        print("seed %d ok: %d documents checked, %.0f s" % (seed, total_docs, time.time() - t0), flush=True)
+print("SOAK OK: %d seeds, %d documents, %.0f s" % (n_seeds, total_docs, time.time() - t0))

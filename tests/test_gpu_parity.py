@@ -455,3 +455,14 @@ def test_many_small_documents(gpu, oracle_models):
     res, tot = run_batch(gpu("tokenizer_de.matok"), piece, cuts)
     assert tot["n_docs"] == len(cuts) - 1
     assert assert_batch_equals_oracle(oracle_models("tokenizer_de.matok"), res, piece, cuts) > 8192
+
+
+def test_event_buffer_rounding(gpu, oracle_models):
+    """A batch created for exactly its input: the event arrays are rounded up to 256 B per run, which must
+    fit the allocation for every size (found by scripts/soak.py: total + 4 n_docs + 4 = 1..3 mod 256)."""
+    from datok_amd import corpus
+    for n in (249, 250, 251, 252, 505, 1017):
+        text, off = corpus.concat_docs([b"ab " * (n // 3) + b"c" * (n % 3)])
+        assert len(text) == n
+        res, _ = run_batch(gpu("tokenizer_de.matok"), text, off)
+        assert_batch_equals_oracle(oracle_models("tokenizer_de.matok"), res, text, off)
