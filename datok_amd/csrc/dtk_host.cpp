@@ -737,6 +737,7 @@ struct dtk_batch {
   hipEvent_t ev[DTK_N_STAGES + 1] = {};
   // last run
   bool ran = false, totals_valid = false;
+  uint32_t exp_runs = 0;  // DTK_EXP_SKIP experiments only
   DtkCompactArgs last_args{};
   dtk_totals totals{};
   // host mirrors for dtk_batch_result_host
@@ -1019,6 +1020,14 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
   hipStream_t s = b->stream;
   const bool prof = b->profiling;
 #define STAGE(i) do { if (prof) HIP_TRY(hipEventRecord(b->ev[i], s)); } while (0)
+#ifdef DTK_EXPERIMENTS
+  // knock-out timing (scripts/knockout.sh): from the second run on, skip the stages named by the
+  // bit mask; with an unchanged input their outputs of the first run are still valid
+  static const int exp_skip = getenv("DATOK_EXP_SKIP") ? atoi(getenv("DATOK_EXP_SKIP")) : 0;
+  const int skip = b->exp_runs++ > 0 ? exp_skip : 0;
+#else
+  const int skip = 0;
+#endif
   STAGE(0);
   {
     // carve the accumulator block for this run's document count: totals, counts, status,
@@ -1037,11 +1046,11 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
     b->d_evA = b->d_ev;
     b->d_evB = b->d_ev + ev_bytes;
 #ifndef DTK_EXP_NO_MEMSET
-    HIP_TRY(hipMemsetAsync(b->d_ev, 0, 2 * ev_bytes, s));
+    if (!(skip & 4)) HIP_TRY(hipMemsetAsync(b->d_ev, 0, 2 * ev_bytes, s));
 #endif
   }
   STAGE(1);
-  if (dtk_launch_symbolize(b->d_text, b->d_off, b->n_docs, b->total, &m->sig, b->d_sym,
+  if (!(skip & 1) && dtk_launch_symbolize(b->d_text, b->d_off, b->n_docs, b->total, &m->sig, b->d_sym,
                            b->d_text == b->d_text_own, b->d_blk_doc, (unsigned long long *)(b->d_totals + 6), b->d_rsbits, s))
     return hip_fail(hipGetLastError(), "symbolize");
   STAGE(2);
@@ -1054,6 +1063,7 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
     DtkSpecArgs sp = spec_args(b, false);
     uint32_t *n_bad = (uint32_t *)(b->d_totals + 5);
     for (int stage = 0; stage < 5; stage++) {
+      if (((skip & 2) && stage <= 1) || ((skip & 4) && stage == 2)) { STAGE(3 + stage); continue; }
       if (dtk_launch_spec(&m->tab, &w, &sp, stage, cmp_mask_of(m), b->d_redo, n_bad, s))
         return hip_fail(hipGetLastError(), "speculative walk");
       STAGE(3 + stage);  // ends: start records, link, chunk walk, verify, fix
@@ -1071,7 +1081,7 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
     return hip_fail(hipGetLastError(), "scan");
   STAGE(8);
   b->last_args = c;
-  int rc = launch_compact2(b);
+  int rc = (skip & 8) ? DTK_OK : launch_compact2(b);
   if (rc != DTK_OK) return rc;
   STAGE(9);
 #undef STAGE
