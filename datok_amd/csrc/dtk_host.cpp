@@ -1045,9 +1045,7 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
     const size_t ev_bytes = (b->total + 4 * nd + 4 + 255) & ~(size_t)255;
     b->d_evA = b->d_ev;
     b->d_evB = b->d_ev + ev_bytes;
-#ifndef DTK_EXP_NO_MEMSET
     if (!(skip & 4)) HIP_TRY(hipMemsetAsync(b->d_ev, 0, 2 * ev_bytes, s));
-#endif
   }
   STAGE(1);
   if (!(skip & 1) && dtk_launch_symbolize(b->d_text, b->d_off, b->n_docs, b->total, &m->sig, b->d_sym,

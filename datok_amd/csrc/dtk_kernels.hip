@@ -404,9 +404,7 @@ struct EventSink {
     // more additionally marks its start in the opening byte of its first position (a SentenceEnd
     // may have fired at that cursor before: same byte, stored by this lane)
     const uint32_t bl = p - tp;
-#ifndef DTK_EXP_NO_EVA
     evA[p] = (uint8_t)(bits | ((bl < EV_LEN_LONG ? bl : EV_LEN_LONG) << EV_LEN_SHIFT));
-#endif
     if (bl >= EV_LEN_LONG) evB[tp] = (uint8_t)(EV_TOK_START | (tp == last_s_p ? s_bits : 0u));
   }
   // SentenceEnd? + TextEnd fired by an EOT rune -- matrix.go:593-600
@@ -1396,10 +1394,8 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
 
     {
       if (isEnd && tok_base + k < tok_lim) {
-#ifndef DTK_EXP_NO_BSTORE
         A.tok_bstart[tok_base + k] = startP;
         A.tok_bend[tok_base + k] = P;
-#endif
         A.tok_rstart[tok_base + k] = rstart;
         A.tok_rend[tok_base + k] = rend;
         if (A.tok_sbefore) A.tok_sbefore[tok_base + k] = sBeforeEnd;  // SentenceEnd calls before this Token call
