@@ -38,8 +38,8 @@
 #define EV_SMASK (EV_S_EOT | EV_S_EPS | EV_S_EPS2 | EV_S_EOF)
 #define EV_EMASK (EV_E_EOT | EV_E_EOF)
 
-// Index of position 0 of document d (starting at input byte `off`) in the event /
-// token-length arrays: 4-byte aligned so that four positions load as one dword, and
+// Index of position 0 of document d (starting at input byte `off`) in the two event
+// arrays: 4-byte aligned so that four positions load as one dword, and
 // one position more than the document has bytes.  Needs total + 4 * n_docs + 4 slots.
 #define DTK_EV_BASE(off, d) ((((uint64_t)(off)) + 4ull * (uint64_t)(d)) & ~3ull)
 

@@ -1191,9 +1191,10 @@ __global__ __launch_bounds__(WAVE) void k_spec_clear(DtkWalkArgs A, DtkSpecArgs 
 #define CQ_CAP 512u  // ring capacity in events (power of two; one light tile adds at most 256)
 
 // One wave per document.  Light phase: 256 cursor positions per iteration (4 per
-// lane) -- OR the two event bytes, count rune starts, and append the positions
-// that carry events (about 0.3 per input byte) with their rune index to a ring in
-// LDS, using one packed wave scan.  Heavy phase: whenever 64 events are queued
+// lane) -- combine the two event bytes (closing bits | opening bits, the token length
+// field of the closing byte kept aside), count rune starts from the bitmap, and append
+// the positions that carry events (about 0.3 per input byte) with their rune index to a
+// ring in LDS, using one packed wave scan.  Heavy phase: whenever 64 events are queued
 // (or at the end), lane i takes the i-th event and everything NewTokenWriter
 // tracks (token_writer.go:38-42: posC, pos, sentB, sent) is recovered with ballots,
 // popcounts of the lanes below and a handful of shuffles; wave-uniform carries link
