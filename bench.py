@@ -157,7 +157,7 @@ def main():
         bb.set_profiling(False)
 
     # ---- offset gather to rank 0 over RCCL (config 5's exchange), outside the clock
-    gather_ms = None
+    gather_ms, gather_hung = None, False
     if world > 1:
         from datok_amd import shard
         v = batch.result_device()
@@ -176,18 +176,31 @@ def main():
                 "sent": dev_i32(v.sent, nsent)}
         torch.cuda.synchronize()
         dist.barrier()
-        g0 = time.perf_counter()
-        try:
-            got = shard.gather_offsets(mine, rank, world, dist, device=dev)
-            torch.cuda.synchronize()
-            gather_ms = (time.perf_counter() - g0) * 1e3
-            if rank == 0:
-                assert sum(int(t.numel()) for t in got["tok_rstart"]) >= ntok
-            del got
-        except Exception as e:  # the gather is outside the timed region: report, do not lose the run
-            print("bench.py: offset gather failed on rank %d: %r" % (rank, e), file=sys.stderr)
-            gather_ms = None
-        dist.barrier()
+        # The gather runs in a helper thread with a deadline: it is outside the timed region, and a
+        # point-to-point problem between two GPUs must not cost the measured line.
+        import threading
+        box = {}
+
+        def _gather():
+            try:
+                torch.cuda.set_device(dev)
+                g0 = time.perf_counter()
+                got = shard.gather_offsets(mine, rank, world, dist, device=dev)
+                torch.cuda.synchronize()
+                box["ms"] = (time.perf_counter() - g0) * 1e3
+                if rank == 0:
+                    assert sum(int(t.numel()) for t in got["tok_rstart"]) >= ntok
+            except Exception as e:  # report, do not lose the run
+                box["err"] = repr(e)
+        th = threading.Thread(target=_gather, daemon=True)
+        th.start()
+        th.join(timeout=float(os.environ.get("DATOK_GATHER_TIMEOUT", "90")))
+        gather_hung = th.is_alive()
+        if gather_hung or "err" in box:
+            print("bench.py: offset gather %s on rank %d" % ("timed out" if gather_hung else "failed: " + box["err"], rank),
+                  file=sys.stderr)
+        gather_ms = box.get("ms")
+        # no barrier behind the gather: a rank whose peer is stuck must still get to its output
 
     # ---- CPU baseline: the C restatement of the Go algorithm, rank 0, N = 1 only
     cpu = None
@@ -258,6 +271,9 @@ def main():
         }
         print(json.dumps(out))
     if world > 1:
+        if gather_hung:
+            sys.stdout.flush()
+            os._exit(0)  # a stuck point-to-point operation would also block the teardown
         dist.destroy_process_group()
 
 
