@@ -705,6 +705,12 @@ struct dtk_batch {
   bool plan_valid = false;
   uint32_t n_lanes = 0, lane_cap = 0;
   uint32_t *d_lane_doc = nullptr, *d_chunk_off = nullptr, *d_redo = nullptr;
+  // long documents are compacted in segments of DTK_SEG_LANES lanes (tables built with the lane plan)
+  uint32_t *d_seg_tab = nullptr;     // seg_doc | seg_lane0 | seg_nl | doc_seg0
+  DtkSegSum *d_seg_sum = nullptr;
+  DtkSegIn *d_seg_in = nullptr;
+  uint32_t n_segs = 0, seg_cap = 0;
+  bool long_docs = false;            // some document has more than one segment
   uint32_t *d_blk_doc = nullptr;     // document of the first byte of every 4 KiB input block
   uint32_t *d_first_bad = nullptr, *d_fail_lane = nullptr;
   DtkLaneCount *d_lane_cnt = nullptr;
@@ -826,6 +832,7 @@ extern "C" void dtk_batch_free(dtk_batch *b) {
   if (b->stream) (void)hipStreamSynchronize(b->stream);
   void *ptrs[] = {b->d_text_own, b->d_off_own, b->d_sym, b->d_rsbits, b->d_ev, b->d_acc, b->d_redo, b->d_chunk_off, b->d_blk_doc,
                   b->d_lane_doc, b->d_lane_cnt, b->d_lane_start, b->d_lane_end, b->d_lane_plan,
+                  b->d_seg_tab, b->d_seg_sum, b->d_seg_in,
                   b->d_tok_off,
                   b->d_sent_off, b->d_text_off, b->d_rstart, b->d_rend, b->d_sent,
                   b->d_bstart, b->d_bend, b->d_ttok, b->d_tsent,
@@ -954,7 +961,38 @@ static int plan_lanes(dtk_batch *b) {
     HIP_TRY(hipMalloc((void **)&b->d_lane_plan, cap * sizeof(DtkLanePlan)));
     b->lane_cap = (uint32_t)cap;
   }
+  // segments of DTK_SEG_LANES lanes: the unit of k_compact for documents with many lanes
+  std::vector<uint32_t> seg_doc, seg_lane0, seg_nl, doc_seg0((size_t)nd + 1);
+  b->long_docs = false;
+  for (uint32_t d = 0; d < nd; d++) {
+    doc_seg0[d] = (uint32_t)seg_doc.size();
+    const uint32_t L0 = chunk_off[d], L1 = chunk_off[d + 1];
+    if (L1 - L0 > DTK_SEG_LANES) b->long_docs = true;
+    for (uint32_t L = L0; L < L1; L += DTK_SEG_LANES) {
+      seg_doc.push_back(d);
+      seg_lane0.push_back(L);
+      seg_nl.push_back(std::min<uint32_t>(DTK_SEG_LANES, L1 - L));
+    }
+  }
+  doc_seg0[nd] = (uint32_t)seg_doc.size();
+  const uint32_t ns = (uint32_t)seg_doc.size();
+  if (ns > b->seg_cap) {
+    void *old[] = {b->d_seg_tab, b->d_seg_sum, b->d_seg_in};
+    for (void *p : old)
+      if (p) HIP_TRY(hipFree(p));
+    b->d_seg_tab = nullptr; b->d_seg_sum = nullptr; b->d_seg_in = nullptr;
+    const uint64_t cap = (uint64_t)ns + ns / 8 + 64;
+    HIP_TRY(hipMalloc((void **)&b->d_seg_tab, (3 * cap + b->max_docs + 1) * 4));
+    HIP_TRY(hipMalloc((void **)&b->d_seg_sum, cap * sizeof(DtkSegSum)));
+    HIP_TRY(hipMalloc((void **)&b->d_seg_in, cap * sizeof(DtkSegIn)));
+    b->seg_cap = (uint32_t)cap;
+  }
+  b->n_segs = ns;
   HIP_TRY(hipStreamSynchronize(b->stream));
+  HIP_TRY(hipMemcpy(b->d_seg_tab, seg_doc.data(), (size_t)ns * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(b->d_seg_tab + b->seg_cap, seg_lane0.data(), (size_t)ns * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(b->d_seg_tab + 2 * (size_t)b->seg_cap, seg_nl.data(), (size_t)ns * 4, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(b->d_seg_tab + 3 * (size_t)b->seg_cap, doc_seg0.data(), ((size_t)nd + 1) * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(b->d_lane_doc, lane_doc.data(), lanes * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(b->d_chunk_off, chunk_off.data(), ((size_t)nd + 1) * 4, hipMemcpyHostToDevice));
   b->n_lanes = (uint32_t)lanes;
@@ -1003,7 +1041,16 @@ static int launch_compact2(dtk_batch *b) {
   a.tok_sbefore = ro ? nullptr : b->d_sbefore; a.text_s_end = ro ? nullptr : b->d_ts_end;
   a.doc_ns = ro ? nullptr : b->d_doc_ns;
   a.tok_cap = b->tok_cap; a.sent_cap = b->sent_cap; a.text_cap = b->text_cap;
+  // a document of many lanes is compacted by one wave per DTK_SEG_LANES lanes (matrix walk: the
+  // double array keeps its window over an EOT, datok.go:1019-1030, so its carries are not closed-form)
+  const bool seg = b->chunk != 0 && b->long_docs && b->last_model && b->last_model->kind == DTK_KIND_MATRIX;
+  a.seg_doc = seg ? b->d_seg_tab : nullptr;
+  a.seg_lane0 = b->d_seg_tab + b->seg_cap; a.seg_nl = b->d_seg_tab + 2 * (size_t)b->seg_cap;
+  a.n_segs = b->n_segs; a.chunk_off = b->d_chunk_off; a.lane_start = b->d_lane_start; a.lane_cnt = b->d_lane_cnt;
+  a.seg_sum = b->d_seg_sum; a.seg_in = b->d_seg_in;
   b->last_args = a;
+  if (seg && dtk_launch_seg_prepare(&a, b->d_seg_tab + 3 * (size_t)b->seg_cap, b->stream))
+    return hip_fail(hipGetLastError(), "segment carries");
   if (dtk_launch_compact(&a, 2, b->stream)) return hip_fail(hipGetLastError(), "compact pass 2");
   return DTK_OK;
 }

@@ -111,6 +111,9 @@ struct DtkLanePlan {
 struct DtkLaneCount {
   uint32_t tok, sent, text;  // Token calls, ints of the sentence list, TextEnd calls
   uint32_t status;
+  // for compacting a long document in segments (k_seg_*): SentenceEnd calls, and the lane's last
+  // TextEnd fired by an EOT: its position (0xFFFFFFFF = none) and the lane's Token calls before it
+  uint32_t sev, e_pos, e_tok, pad;
 };
 struct DtkSpecArgs {
   uint32_t n_lanes;
@@ -160,6 +163,29 @@ struct DtkCompactArgs {
   uint32_t *tok_sbefore, *text_s_end, *doc_ns;
   const uint64_t *totals;   // [0..2] tokens, sentence ints, texts (written by the scan)
   uint64_t tok_cap, sent_cap, text_cap;
+  // Long documents are compacted in segments of DTK_SEG_LANES chunk lanes (matrix walk with chunk
+  // lanes only; null = one wave per document): segment -> document / first lane / lanes
+  const uint32_t *seg_doc, *seg_lane0, *seg_nl;
+  uint32_t n_segs;
+  const uint32_t *chunk_off;              // document -> first lane
+  const struct DtkLaneState *lane_start;  // sync points = where segments begin
+  const struct DtkLaneCount *lane_cnt;
+  struct DtkSegSum *seg_sum;              // k_seg_sum: what a segment adds
+  struct DtkSegIn *seg_in;                // k_seg_scan: the carries a segment starts with
+};
+
+#define DTK_SEG_LANES 64u
+// what the lanes of one segment add up to (k_seg_sum)
+struct DtkSegSum {
+  uint32_t tok, sent, text, sev;  // Token calls, sentence ints, TextEnd calls, SentenceEnd calls
+  uint32_t runes;                 // rune starts in the segment's positions
+  uint32_t e_pos;                 // last EOT TextEnd inside (0xFFFFFFFF: none) ...
+  uint32_t e_tok, e_runes;        // ... Token calls / rune starts of the segment before it
+};
+// the state k_compact starts a segment with: everything that precedes it in the document
+struct DtkSegIn {
+  uint32_t tok, sent, text, sev, runes;
+  uint32_t e_pos, e_tok, e_runes;  // last EOT TextEnd before the segment (absolute), 0xFFFFFFFF: none
 };
 
 // NewTokenWriter's byte output on the device (dtk_render.hip)
@@ -200,6 +226,7 @@ int dtk_launch_spec(const struct DtkTableDev *tab, const struct DtkWalkArgs *arg
                     const struct DtkSpecArgs *spec, int stage, uint32_t cmp_mask, uint32_t *redo_out,
                     uint32_t *n_bad, void *stream);
 int dtk_launch_compact(const struct DtkCompactArgs *args, int pass, void *stream);
+int dtk_launch_seg_prepare(const struct DtkCompactArgs *args, const uint32_t *doc_seg0, void *stream);
 int dtk_launch_render(const struct DtkRenderArgs *args, int stage, void *stream);
 uint32_t dtk_render_tiles(uint64_t n);
 int dtk_launch_scan3(const uint64_t *ca, const uint64_t *cb, const uint64_t *cc, uint64_t *a, uint64_t *b,

@@ -383,10 +383,13 @@ struct EventSink {
   // what NewTokenWriter would have collected from this lane's calls
   // (token_writer.go:72-81, 104-109, 131-159): tokens, ints of the sentence list, texts
   uint32_t c_tok, c_sent, c_text;
+  uint32_t c_sev;         // SentenceEnd calls (all of them, also where the reference would panic)
+  uint32_t e_pos, e_tok;  // the last EOT TextEnd of this lane: position, Token calls before it
   __device__ __forceinline__ void init(uint8_t *a, uint8_t *b, uint32_t wlo, uint32_t whi) {
     evA = a; evB = b; lo = wlo; hi = whi;
     last_s_p = last_eot_p = 0xFFFFFFFFu; s_bits = eot_bits = 0; st = 0; dropped = 0;
     c_tok = c_sent = c_text = 0;
+    c_sev = 0; e_pos = 0xFFFFFFFFu; e_tok = 0;
   }
   __device__ __forceinline__ bool in_closing(uint32_t p) const { return p > lo && p <= hi; }
   __device__ __forceinline__ bool in_opening(uint32_t p) const { return p >= lo && p < hi; }
@@ -413,6 +416,8 @@ struct EventSink {
   __device__ __forceinline__ void eot(uint32_t p, bool with_sentence, bool has_tok) {
     if (!in_closing(p)) { dropped = 1; return; }
     c_text++;
+    c_sev += with_sentence ? 1u : 0u;
+    e_pos = p; e_tok = c_tok;
     if (has_tok) c_sent += with_sentence ? 1u : 0u; else st |= ST_EMPTY_TEXT;
     if (!IS_MATRIX && p == last_eot_p) st |= ST_IRREGULAR;  // the same EOT consumed twice
     const uint32_t bits = EV_E_EOT | (with_sentence ? EV_S_EOT : 0u);
@@ -422,6 +427,7 @@ struct EventSink {
   // SentenceEnd from an epsilon arc on an empty token -- matrix.go:574-575
   __device__ __forceinline__ void sentence(uint32_t p, bool has_tok) {
     if (!in_opening(p)) { dropped = 1; return; }
+    c_sev++;
     if (has_tok) c_sent++; else st |= ST_EMPTY_TEXT;
     if (p == last_s_p) {
       if (s_bits & EV_S_EPS2) st |= ST_IRREGULAR;
@@ -438,6 +444,7 @@ struct EventSink {
     if (!bits) return;
     if (!in_opening(p)) { dropped = 1; return; }
     if (!text_end) c_text++;
+    c_sev += sentence_end ? 0u : 1u;
     if (has_tok) c_sent += sentence_end ? 0u : 1u; else st |= ST_EMPTY_TEXT;
     evB[p] = (uint8_t)(bits | (p == last_s_p ? s_bits : 0u));
   }
@@ -1038,7 +1045,7 @@ __global__ __launch_bounds__(WAVE) void k_spec_walk(TRANS tr, DtkWalkArgs A, Dtk
     if (!redo || (S.redo_from[d] != 0xFFFFFFFFu && L >= S.redo_from[d])) {
       const DtkLanePlan pl = plan_of(S, L, d);
       DtkLaneState fin{0xFFFFFFFFu, 0u, 0u, LANE_F_IDLE};
-      DtkLaneCount cnt{0u, 0u, 0u, 0u};
+      DtkLaneCount cnt{0u, 0u, 0u, 0u, 0u, 0xFFFFFFFFu, 0u, 0u};
       if (pl.mode != PLAN_OFF) {
         const uint64_t off = A.doc_off[d];
         const uint32_t len = (uint32_t)(A.doc_off[d + 1] - off);
@@ -1051,6 +1058,7 @@ __global__ __launch_bounds__(WAVE) void k_spec_walk(TRANS tr, DtkWalkArgs A, Dtk
                                                 identity, step_cap(A.step_factor, len), fin, st, steps);
         if (sink.dropped) fin.flags |= LANE_F_DROPPED;
         cnt.tok = sink.c_tok; cnt.sent = sink.c_sent; cnt.text = sink.c_text; cnt.status = st | sink.st;
+        cnt.sev = sink.c_sev; cnt.e_pos = sink.e_pos; cnt.e_tok = sink.e_tok;
       }
       S.lane_end[L] = fin;
       S.lane_cnt[L] = cnt;
@@ -1066,7 +1074,7 @@ __global__ __launch_bounds__(256) void k_spec_verify(DtkWalkArgs A, DtkSpecArgs 
   const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = L < S.n_lanes;  // every lane stays for the wave reduction below
   uint32_t d = 0xFFFFFFFFu;
-  DtkLaneCount c{0u, 0u, 0u, 0u};
+  DtkLaneCount c{0u, 0u, 0u, 0u, 0u, 0xFFFFFFFFu, 0u, 0u};
   if (live) {
     d = S.lane_doc[L];
     const uint32_t L0 = S.chunk_off[d];
@@ -1199,10 +1207,26 @@ __global__ __launch_bounds__(WAVE) void k_spec_clear(DtkWalkArgs A, DtkSpecArgs 
 // tracks (token_writer.go:38-42: posC, pos, sentB, sent) is recovered with ballots,
 // popcounts of the lanes below and a handful of shuffles; wave-uniform carries link
 // the rounds.  Order of the calls at one position = bit order of the event byte.
+// Range of one segment of a long document: closing events in (p0, p1], opening events in
+// [p0, p1) -- or [p0, p1] for the document's last segment.  false: nothing to do.
+struct SegRange { uint32_t d, p0, p1; bool first, last; };
+__device__ __forceinline__ bool seg_range(const DtkCompactArgs &A, uint32_t s, uint32_t len_of_d, SegRange &r) {
+  const uint32_t La = A.seg_lane0[s], Lb = La + A.seg_nl[s];
+  const uint32_t L0 = A.chunk_off[r.d], L1 = A.chunk_off[r.d + 1];
+  r.first = La == L0;
+  r.last = Lb >= L1;
+  r.p0 = r.first ? 0u : A.lane_start[La].p;
+  if (r.p0 == 0xFFFFFFFFu) return false;  // the lane chain reached the end of the document before
+  r.p1 = r.last ? len_of_d : A.lane_start[Lb].p;
+  if (r.p1 == 0xFFFFFFFFu) { r.p1 = len_of_d; r.last = true; }
+  return true;
+}
+
 __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
   __shared__ uint32_t qpos[CQ_CAP], qfl[CQ_CAP], qrn[CQ_CAP];
-  const uint32_t d = blockIdx.x;
-  if (d >= A.n_docs) return;
+  const bool seg_mode = A.seg_doc != nullptr;
+  if (blockIdx.x >= (seg_mode ? A.n_segs : A.n_docs)) return;
+  const uint32_t d = seg_mode ? A.seg_doc[blockIdx.x] : blockIdx.x;
   const uint64_t off = A.doc_off[d];
   const uint32_t len = (uint32_t)(A.doc_off[d + 1] - off);
   const uint64_t evb = DTK_EV_BASE(off, d);
@@ -1235,16 +1259,56 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
   uint32_t status = 0;
   uint32_t qhead = 0, qn = 0;  // ring: first entry, entries queued
 
-  const uint32_t n_pos = len + 1u;  // cursor positions 0..len
-  for (uint32_t base = 0; base < n_pos; base += 4u * WAVE) {
+  // the positions of this wave: the whole document, or one segment of a long one
+  SegRange sr{d, 0u, len, true, true};
+  if (seg_mode) {
+    if (!seg_range(A, blockIdx.x, len, sr)) return;
+    if (!sr.first) {
+      // Everything the sequential pass would carry into position p0 (a sync point of the walk: the
+      // window was rewound there) follows from the totals of the lanes before it and from the last
+      // EOT TextEnd before it (k_seg_scan).  Matrix walk only (matrix.go:601 rewinds at EOT).
+      const DtkSegIn in = A.seg_in[blockIdx.x];
+      cR = in.runes; cTE = in.tok; cNE = in.text; cNSev = in.sev; cNSent = in.sent;
+      cHaveE = in.e_pos != 0xFFFFFFFFu;
+      if (cHaveE) {
+        cLastER = in.e_runes; cTokAtLastE = in.e_tok;
+        cLastEByte = (nl_rule && in.e_pos < len) ? txt[in.e_pos] : 0u;
+      }
+      // the text that is open at p0 has a token already: its first token fixed the rune base
+      const uint32_t kf = cHaveE ? cTokAtLastE : 0u;
+      if (cTE > kf)
+        cBase = kf == 0u ? (cHaveE ? cLastER : 0u)  // it was the document's first token
+                         : cLastER + ((nl_rule && cLastEByte == '\n') ? 1u : 0u);
+      if (evA[sr.p0] & EV_TOK_END) {  // the rewind at p0 was a token flush: that token is "the last one"
+        cLastEndR = cR;
+        cLastEndByte = (nl_rule && sr.p0 < len) ? txt[sr.p0] : 0u;
+        cSEatEnd = cNSev + cNE; cEatEnd = cNE;
+        cLastRend = (int32_t)(cR - cBase);
+      }  // else an EOT TextEnd: whatever ended before it is behind a call, the zeros above do
+    }
+  }
+
+  const uint32_t n_pos = sr.p1 + 1u;  // cursor positions p0..p1
+  // bytes of a dword at positions q..q+3 that lie in [a, b]
+  auto in_range = [](uint32_t q, uint32_t a, uint32_t b) -> uint32_t {
+    if (q + 3u < a || q > b) return 0u;
+    const uint32_t first = a > q ? a - q : 0u, last = b - q < 3u ? b - q : 3u;
+    return (0xFFFFFFFFu >> (8u * (3u - last))) & (0xFFFFFFFFu << (8u * first));
+  };
+  for (uint32_t base = sr.p0 & ~3u; base < n_pos; base += 4u * WAVE) {
     // ---- light phase
     const uint32_t P0 = base + lane * 4u;
     uint32_t fw = 0, lw = 0, rsn = 0;  // 4 event bytes (one per position), token length fields, rune-start nibble
     if (P0 < n_pos) {
       // DTK_EV_BASE is 4-byte aligned and the arrays are padded: whole dwords are readable,
       // bytes behind position `len` are zero (cleared, never written)
-      const uint32_t fa = *reinterpret_cast<const uint32_t *>(evA + P0);
-      fw = (fa & 0x07070707u) | *reinterpret_cast<const uint32_t *>(evB + P0);
+      uint32_t fa = *reinterpret_cast<const uint32_t *>(evA + P0);
+      uint32_t fb = *reinterpret_cast<const uint32_t *>(evB + P0);
+      if (seg_mode) {  // closing events in (p0, p1], opening events in [p0, p1) or, at the end, [p0, p1]
+        fa &= in_range(P0, sr.p0 + 1u, sr.p1);
+        fb &= sr.last ? in_range(P0, sr.p0, sr.p1) : (sr.p1 > sr.p0 ? in_range(P0, sr.p0, sr.p1 - 1u) : 0u);
+      }
+      fw = (fa & 0x07070707u) | fb;
       lw = (fa >> EV_LEN_SHIFT) & 0x1F1F1F1Fu;
       const uint32_t left = n_pos - P0;  // positions of mine that exist
       if (left < 4u) fw &= (1u << (8u * left)) - 1u;
@@ -1254,6 +1318,7 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
       const uint64_t two = (uint64_t)wp[0] | ((uint64_t)wp[1] << 32);
       const uint32_t have = len > P0 ? (len - P0 >= 4u ? 4u : len - P0) : 0u;
       rsn = (uint32_t)(two >> (g0 & 31u)) & ((1u << have) - 1u);
+      if (P0 < sr.p0) rsn &= ~((1u << (sr.p0 - P0)) - 1u);  // runes before p0 are in the carry
     }
     const uint32_t evn = ((fw & 0xFFu) ? 1u : 0u) | ((fw & 0xFF00u) ? 2u : 0u) | ((fw & 0xFF0000u) ? 4u : 0u) |
                          ((fw & 0xFF000000u) ? 8u : 0u);
@@ -1464,13 +1529,103 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
   for (int o = 32; o > 0; o >>= 1) sred |= __shfl_down(sred, o);
   sred = __shfl(sred, 0);
   if (lane == 0) {
-    if (tok_base + cTE != tok_lim || sent_base + cNSent != sent_lim || text_base + cNE != text_lim)
+    if (sr.last && (tok_base + cTE != tok_lim || sent_base + cNSent != sent_lim || text_base + cNE != text_lim))
       sred |= ST_INTERNAL;
     sred &= ST_INTERNAL;  // everything else was reported by the walk already
     if (sred) atomicOr(&A.status[d], sred);
-    if (A.doc_ns) A.doc_ns[d] = cNSev;  // SentenceEnd calls of this document (for rendering)
+    if (sr.last && A.doc_ns) A.doc_ns[d] = cNSev;  // SentenceEnd calls of this document (for rendering)
   }
 }
+
+// ---- long documents: what each segment adds (k_seg_sum), then per document an exclusive scan of
+//      the segments (k_seg_scan) -> the carries k_compact starts a segment with
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// rune starts among the input bytes [g0, g1) (bit g of rs_bits = byte g), all lanes take part
+__device__ __forceinline__ uint32_t runes_between(const uint32_t *__restrict__ bits, uint64_t g0, uint64_t g1) {
+  uint32_t n = 0;
+  if (g1 > g0) {
+    const uint64_t w0 = g0 >> 5, wl = (g1 - 1) >> 5;  // first and last word touched
+    for (uint64_t w = w0 + lane_id(); w <= wl; w += WAVE) {
+      uint32_t x = bits[w];
+      if (w == w0) x &= 0xFFFFFFFFu << (g0 & 31u);
+      if (w == wl && (g1 & 31u)) x &= (1u << (g1 & 31u)) - 1u;
+      n += (uint32_t)__popc(x);
+    }
+  }
+  return wave_sum(n);
+}
+
+__global__ __launch_bounds__(WAVE) void k_seg_sum(DtkCompactArgs A) {
+  const uint32_t s = blockIdx.x;
+  if (s >= A.n_segs) return;
+  const uint32_t d = A.seg_doc[s];
+  if (A.chunk_off[d + 1] - A.chunk_off[d] <= DTK_SEG_LANES) return;  // a single segment needs no carry
+  const uint64_t off = A.doc_off[d];
+  const uint32_t len = (uint32_t)(A.doc_off[d + 1] - off);
+  const uint32_t lane = lane_id();
+  DtkSegSum o{0u, 0u, 0u, 0u, 0u, 0xFFFFFFFFu, 0u, 0u};
+  SegRange sr{d, 0u, len, true, true};
+  if (seg_range(A, s, len, sr)) {
+    const uint32_t La = A.seg_lane0[s], nl = A.seg_nl[s];
+    DtkLaneCount c{0u, 0u, 0u, 0u, 0u, 0xFFFFFFFFu, 0u, 0u};
+    if (lane < nl) c = A.lane_cnt[La + lane];
+    uint32_t tot;
+    const uint32_t tok_before = wave_excl_scan(c.tok, tot);  // Token calls of the segment's earlier lanes
+    o.tok = tot;
+    o.sent = wave_sum(c.sent); o.text = wave_sum(c.text); o.sev = wave_sum(c.sev);
+    o.runes = runes_between(A.rs_bits, off + sr.p0, off + sr.p1);
+    const unsigned long long mE = __ballot(c.e_pos != 0xFFFFFFFFu);
+    if (mE) {  // the last lane with an EOT TextEnd
+      const int j = highest(mE);
+      o.e_pos = __shfl(c.e_pos, j);
+      o.e_tok = __shfl(tok_before + c.e_tok, j);
+      o.e_runes = runes_between(A.rs_bits, off + sr.p0, off + o.e_pos);
+    }
+  }
+  if (lane == 0) A.seg_sum[s] = o;
+}
+
+// one wave per document with more than one segment: exclusive scan of its segment sums
+__global__ __launch_bounds__(WAVE) void k_seg_scan(DtkCompactArgs A, const uint32_t *doc_seg0) {
+  const uint32_t d = blockIdx.x;
+  if (d >= A.n_docs) return;
+  const uint32_t s0 = doc_seg0[d], s1 = doc_seg0[d + 1];
+  if (s1 - s0 <= 1u) return;
+  const uint32_t lane = lane_id();
+  uint32_t bt = 0, bs = 0, bx = 0, bv = 0, br = 0;        // running totals before the current group of 64
+  uint32_t ce_pos = 0xFFFFFFFFu, ce_tok = 0, ce_runes = 0;  // last EOT TextEnd so far (absolute)
+  for (uint32_t g = s0; g < s1; g += WAVE) {
+    const uint32_t s = g + lane;
+    DtkSegSum v{0u, 0u, 0u, 0u, 0u, 0xFFFFFFFFu, 0u, 0u};
+    if (s < s1) v = A.seg_sum[s];
+    uint32_t tt, ts, tx, tv, tr;
+    const uint32_t et = wave_excl_scan(v.tok, tt), es = wave_excl_scan(v.sent, ts), ex = wave_excl_scan(v.text, tx);
+    const uint32_t ev = wave_excl_scan(v.sev, tv), er = wave_excl_scan(v.runes, tr);
+    // last EOT TextEnd before my segment: the nearest lower lane of this group that has one, else the carry
+    const unsigned long long mE = __ballot(v.e_pos != 0xFFFFFFFFu);
+    const unsigned long long below = mE & lanemask_lt();
+    const int j = below ? highest(below) : 0;
+    const uint32_t jp = __shfl(v.e_pos, j), jt = __shfl(bt + et + v.e_tok, j), jr = __shfl(br + er + v.e_runes, j);
+    if (s < s1) {
+      DtkSegIn in;
+      in.tok = bt + et; in.sent = bs + es; in.text = bx + ex; in.sev = bv + ev; in.runes = br + er;
+      in.e_pos = below ? jp : ce_pos; in.e_tok = below ? jt : ce_tok; in.e_runes = below ? jr : ce_runes;
+      A.seg_in[s] = in;
+    }
+    if (mE) {
+      const int jl = highest(mE);
+      ce_pos = __shfl(v.e_pos, jl); ce_tok = __shfl(bt + et + v.e_tok, jl); ce_runes = __shfl(br + er + v.e_runes, jl);
+    }
+    bt += tt; bs += ts; bx += tx; bv += tv; br += tr;
+  }
+}
+
 
 // ------------------------------------------------------- exclusive scan (x3)
 //
@@ -1616,7 +1771,15 @@ extern "C" int dtk_launch_compact(const DtkCompactArgs *args, int pass, void *st
   if (args->n_docs == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   (void)pass;
-  hipLaunchKernelGGL(k_compact, dim3(args->n_docs), dim3(WAVE), 0, s, *args);
+  hipLaunchKernelGGL(k_compact, dim3(args->seg_doc ? args->n_segs : args->n_docs), dim3(WAVE), 0, s, *args);
+  return (int)hipGetLastError();
+}
+
+// the carries of the segments of long documents (before dtk_launch_compact in segment mode)
+extern "C" int dtk_launch_seg_prepare(const DtkCompactArgs *args, const uint32_t *doc_seg0, void *stream) {
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_seg_sum, dim3(args->n_segs), dim3(WAVE), 0, s, *args);
+  hipLaunchKernelGGL(k_seg_scan, dim3(args->n_docs), dim3(WAVE), 0, s, *args, doc_seg0);
   return (int)hipGetLastError();
 }
 

@@ -40,6 +40,19 @@ def random_docs(rng, n):
     return corpus.concat_docs(docs)
 
 
+def long_docs(rng, n):
+    out = []
+    for _ in range(n):
+        text, off = random_docs(rng, int(rng.integers(40, 200)))
+        raw = bytearray(text.tobytes())
+        if rng.integers(0, 2):
+            g, _ = corpus.german_docs(int(rng.integers(4, 24)), 4096, seed=int(rng.integers(0, 1 << 30)))
+            cut = int(rng.integers(0, len(raw) + 1))
+            raw[cut:cut] = g.tobytes() + b" \x04\n"
+        out.append(bytes(raw))
+    return corpus.concat_docs(out)
+
+
 models = {name: (datok_amd.load_tokenizer_file(os.path.join(M, name)), O.Model(os.path.join(M, name)))
           for name in ("tokenizer_de.matok", "tokenizer_en.matok", "tokenizer_de.datok", "clitic_test.matok")}
 t0 = time.time()
@@ -49,7 +62,10 @@ for seed in range(first, first + n_seeds):
     cases = [("tokenizer_de.matok", corpus.german_docs(int(rng.integers(64, 600)), int(rng.choice([512, 4096, 9000])), seed=seed)),
              ("tokenizer_en.matok", corpus.english_zipf_docs(int(rng.integers(64, 400)), seed=seed, max_bytes=16384)),
              ("tokenizer_de.datok", corpus.german_docs(128, 4096, seed=seed + 7)),
-             (str(rng.choice(list(models))), random_docs(rng, 300))]
+             (str(rng.choice(list(models))), random_docs(rng, 300)),
+             # a few long documents full of EOT texts, blanks and odd bytes: many compaction segments
+             (str(rng.choice(["tokenizer_de.matok", "tokenizer_en.matok", "clitic_test.matok"])),
+              long_docs(rng, int(rng.integers(1, 4))))]
     for name, (text, off) in cases:
         tok, om = models[name]
         chunk, warm = [(None, 48), (0, 48), (64, 48), (128, 16), (256, 48), (48, 0), (1024, 48)][int(rng.integers(0, 7))]

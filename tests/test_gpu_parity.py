@@ -466,3 +466,44 @@ def test_event_buffer_rounding(gpu, oracle_models):
         assert len(text) == n
         res, _ = run_batch(gpu("tokenizer_de.matok"), text, off)
         assert_batch_equals_oracle(oracle_models("tokenizer_de.matok"), res, text, off)
+
+
+@pytest.mark.parametrize("model", ["tokenizer_de.matok", "clitic_test.matok"])
+@pytest.mark.parametrize("flags,chunk", [(0, 48), (NEWLINE_AFTER_EOT, 128), (NEWLINE_AFTER_EOT, None)])
+def test_long_documents_with_eot_texts_in_segments(gpu, oracle_models, model, flags, chunk):
+    """Documents of many chunk lanes are compacted in segments of 64 lanes whose carries come from the
+    lanes' totals (k_seg_sum / k_seg_scan): long documents stuffed with EOT texts (also several in a row,
+    at the start and at the end), sentence ends and invalid bytes, offsets and rendered text."""
+    import datok_amd
+    from datok_amd import corpus
+    rng = np.random.default_rng(99)
+    docs = []
+    edge = _edge_docs()
+    for k in range(6):
+        parts = [edge[int(i)] for i in rng.integers(0, len(edge), size=int(rng.integers(200, 500)))]
+        parts = [p for p in parts if len(p) < 400]
+        sep = [b" ", b"\n", b"\x04", b"\x04\n", b". ", b"\x04\x04"]
+        raw = b"".join(p + sep[int(rng.integers(0, len(sep)))] for p in parts)
+        if k == 0:
+            raw = b"\x04\x04" + raw
+        if k == 1:
+            raw = raw + b"\x04"
+        docs.append(raw)
+    text, off = corpus.concat_docs(docs)
+    om = oracle_models(model)
+    with datok_amd.Batch(len(text), len(docs)) as b:
+        if chunk is not None:
+            b.set_chunking(chunk, 48)
+        b.set_input(text, off)
+        b.run(gpu(model), flags)
+        res, tot = b.result(), b.totals()
+        assert tot["n_lanes"] > 64 * len(docs)
+        ok = [d for d in range(len(docs)) if not (int(res.status[d]) & ~datok_amd.ST_EMPTY_TEXT)]
+        assert len(ok) >= 1
+        assert_batch_equals_oracle(om, res, text, off, flags, docs=range(len(docs)))
+        for bits in (SIMPLE, 15):
+            data, o = b.render(bits | flags)
+            for d in ok:
+                exp, est = om.transduce(docs[d], bits | flags)
+                if est == 0:
+                    assert data[int(o[d]):int(o[d + 1])] == exp, (model, flags, chunk, bits, d)
