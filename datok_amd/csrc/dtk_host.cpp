@@ -1166,7 +1166,7 @@ static int finish(dtk_batch *b) {
   if (b->totals_valid) return DTK_OK;
   HIP_TRY(hipStreamSynchronize(b->stream));
   // Speculation check failed somewhere: repair those documents from their first bad lane
-  // on (clear, re-plan, re-walk, re-check) until every lane chains, then compact again.
+  // on (fix records, clear, re-link, re-walk, re-verify) until every lane chains, then compact again.
   if (b->chunk != 0 && (uint32_t)b->h_totals[5] != 0) {
     const dtk_model *m = b->last_model;
     hipStream_t s = b->stream;
@@ -1176,8 +1176,11 @@ static int finish(dtk_batch *b) {
       b->repair_rounds++;
       DtkSpecArgs sp = spec_args(b, true);
       HIP_TRY(hipMemsetAsync(n_bad, 0, 8, s));
-      const int order[4] = {5, 6, 2, 7};
-      for (int stage : order)
+      // spread + reset, clear, then the stages of the first pass restricted to what is repaired
+      if (dtk_launch_spec(&m->tab, &w, &sp, 5, cmp_mask_of(m), b->d_redo, n_bad, s) ||
+          dtk_launch_redo_clear(&w, &sp, b->d_blk_doc, b->total, s))
+        return hip_fail(hipGetLastError(), "speculative repair");
+      for (int stage = 1; stage <= 4; stage++)
         if (dtk_launch_spec(&m->tab, &w, &sp, stage, cmp_mask_of(m), b->d_redo, n_bad, s))
           return hip_fail(hipGetLastError(), "speculative repair");
       HIP_TRY(hipMemcpyAsync(b->h_totals + 5, b->d_totals + 5, 8, hipMemcpyDeviceToHost, s));

@@ -225,6 +225,8 @@ int dtk_launch_walk(const struct DtkTableDev *tab, const struct DtkWalkArgs *arg
 int dtk_launch_spec(const struct DtkTableDev *tab, const struct DtkWalkArgs *args,
                     const struct DtkSpecArgs *spec, int stage, uint32_t cmp_mask, uint32_t *redo_out,
                     uint32_t *n_bad, void *stream);
+int dtk_launch_redo_clear(const struct DtkWalkArgs *args, const struct DtkSpecArgs *spec, const uint32_t *blk_doc,
+                          uint64_t total, void *stream);
 int dtk_launch_compact(const struct DtkCompactArgs *args, int pass, void *stream);
 int dtk_launch_seg_prepare(const struct DtkCompactArgs *args, const uint32_t *doc_seg0, void *stream);
 int dtk_launch_render(const struct DtkRenderArgs *args, int stage, void *stream);

@@ -886,10 +886,10 @@ __global__ __launch_bounds__(WAVE) void k_walk_doc(TRANS tr, DtkWalkArgs A, uint
 //   k_spec_start : lane k >= 1 walks from k*C - W in the start state and records
 //                  the first sync point at or after k*C  (the automaton
 //                  re-synchronises within a token or two).
-//   k_spec_plan  : per document, chains the records into windows.
+//   k_spec_link  : per document, the first lane without a linked successor.
 //   k_spec_walk  : each lane walks from its record to the next lane's record,
 //                  storing events inside its window only.
-//   k_spec_check : per document, verifies that every lane arrived exactly at its
+//   k_spec_verify: per lane, verifies that it arrived exactly at its
 //                  successor's record (position, state, flags).  A document that
 //                  fails is repaired from the first bad lane on (host loop,
 //                  normally never entered) -- the result is exact either way.
@@ -953,50 +953,9 @@ __global__ __launch_bounds__(WAVE) void k_spec_start(TRANS tr, DtkWalkArgs A, Dt
   add_steps(A.steps, steps);
 }
 
-// One thread per document: enable the longest prefix of lanes whose records are
-// present and ordered, and give each its window end / stop position.
-__global__ __launch_bounds__(256) void k_spec_plan(DtkWalkArgs A, DtkSpecArgs S) {
-  const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
-  if (d >= A.n_docs) return;
-  const uint32_t L0 = S.chunk_off[d], L1 = S.chunk_off[d + 1];
-  if (S.redo_from[d] == 0xFFFFFFFFu) return;
-  // lanes before the first redone lane are chained by construction (they checked out)
-  const uint32_t first = S.redo_from[d];
-  for (uint32_t L = L0; L < first; L++) {
-    DtkLanePlan pl;
-    pl.stop = pl.wend = S.lane_start[L + 1].p; pl.mode = PLAN_CHAINED; pl.pad = 0;
-    S.lane_plan[L] = pl;
-  }
-  bool enabled = true;
-  for (uint32_t L = first; L < L1; L++) {
-    const uint32_t k = L - L0;
-    bool next_ok = false;
-    uint32_t next_p = 0;
-    if (enabled && L + 1 < L1) {
-      const DtkLaneState nx = S.lane_start[L + 1];
-      next_ok = nx.p != 0xFFFFFFFFu && nx.p >= S.lane_start[L].p;
-      next_p = nx.p;
-    }
-    DtkLanePlan pl;
-    if (!enabled) {
-      pl.stop = 0; pl.wend = 0; pl.mode = PLAN_OFF;
-    } else if (next_ok) {
-      pl.stop = next_p; pl.wend = next_p; pl.mode = PLAN_CHAINED;
-    } else {
-      // last enabled lane: stops at the first sync point behind its own chunk (or EOF)
-      pl.stop = (L + 1 < L1) ? (k + 1u) * S.chunk : 0xFFFFFFFFu;
-      pl.wend = 0xFFFFFFFFu;
-      pl.mode = PLAN_LAST;
-    }
-    S.lane_plan[L] = pl;
-    if (!next_ok) enabled = false;
-  }
-}
-
-// First pass: every lane derives its window from the start records and
-// first_bad[d] (k_spec_link).  Repair rounds: from lane_plan (k_spec_plan).
+// Every lane derives its window from the start records and first_bad[d] (k_spec_link), in the
+// first pass and in repair rounds alike.
 __device__ __forceinline__ DtkLanePlan plan_of(const DtkSpecArgs &S, uint32_t L, uint32_t d) {
-  if (S.redo_from) return S.lane_plan[L];
   const uint32_t L0 = S.chunk_off[d], L1 = S.chunk_off[d + 1];
   const uint32_t k = L - L0, fb = ~S.first_bad[d];
   DtkLanePlan pl;
@@ -1072,13 +1031,17 @@ __global__ __launch_bounds__(WAVE) void k_spec_walk(TRANS tr, DtkWalkArgs A, Dtk
 // first lane that did not is recorded (bit-inverted, zero = none) in fail_lane[d].
 __global__ __launch_bounds__(256) void k_spec_verify(DtkWalkArgs A, DtkSpecArgs S, uint32_t cmp_mask) {
   const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = L < S.n_lanes;  // every lane stays for the wave reduction below
+  bool live = L < S.n_lanes;  // every lane stays for the wave reduction below
   uint32_t d = 0xFFFFFFFFu;
   DtkLaneCount c{0u, 0u, 0u, 0u, 0u, 0xFFFFFFFFu, 0u, 0u};
   if (live) {
     d = S.lane_doc[L];
+    if (S.redo_from && S.redo_from[d] == 0xFFFFFFFFu) { live = false; d = 0xFFFFFFFFu; }  // a repair round: not this document
+  }
+  if (live) {
     const uint32_t L0 = S.chunk_off[d];
     const uint32_t k = L - L0, fb = ~S.first_bad[d];
+    uint32_t link_ok = 1u;  // did I arrive exactly at my successor's record (k_redo_spread reads it)
     if (k > fb) {
       // a lane behind the chain: legitimate only if the chain ran to EOF and I found no sync point
       if (S.lane_start[L].p != 0xFFFFFFFFu) atomicMax(&S.fail_lane[d], ~(L0 + fb));
@@ -1093,7 +1056,9 @@ __global__ __launch_bounds__(256) void k_spec_verify(DtkWalkArgs A, DtkSpecArgs 
         good = en.p == 0xFFFFFFFFu && !(en.flags & LANE_F_IDLE);  // the chain's last lane must reach EOF
       }
       if (good) c = S.lane_cnt[L]; else atomicMax(&S.fail_lane[d], ~L);
+      link_ok = good ? 1u : 0u;
     }
+    S.lane_plan[L].pad = link_ok;
   }
   // The lanes of a document are consecutive: add up the counts of each run of equal
   // documents inside the wave, then one atomic per run instead of one per lane.
@@ -1124,11 +1089,8 @@ __device__ __forceinline__ void mark_redo(const DtkSpecArgs &S, uint32_t d, uint
   const uint32_t L1 = S.chunk_off[d + 1];
   DtkLaneState en = S.lane_end[bad];
   en.flags &= (LANE_F_SENT | LANE_F_TEXT | LANE_F_OK);
-  if (en.p == 0xFFFFFFFFu) {  // ran to EOF: no later lane has a sync point
-    for (uint32_t M = bad + 1; M < L1; M++) S.lane_start[M].p = 0xFFFFFFFFu;
-  } else if (bad + 1 < L1) {
-    S.lane_start[bad + 1] = en;
-  }
+  if (en.p != 0xFFFFFFFFu && bad + 1 < L1) S.lane_start[bad + 1] = en;
+  // (ran to EOF: no later lane has a sync point -- k_redo_spread withdraws their records)
   redo_out[d] = bad;
   atomicAdd(n_bad, 1u);
 }
@@ -1142,55 +1104,69 @@ __global__ __launch_bounds__(256) void k_spec_fix(DtkWalkArgs A, DtkSpecArgs S, 
   mark_redo(S, d, bad, redo_out, n_bad);
 }
 
-// Repair rounds only (one thread per repaired document): did every lane arrive
-// exactly at its successor's record?  If so the document's counts and status are
-// re-assigned from its lanes; otherwise the next bad lane is recorded.
-__global__ __launch_bounds__(256) void k_spec_check(DtkWalkArgs A, DtkSpecArgs S, uint32_t cmp_mask,
-                                                    uint32_t *redo_out, uint32_t *n_bad) {
-  const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
-  if (d >= A.n_docs) return;
-  if (S.redo_from[d] == 0xFFFFFFFFu) return;
-  const uint32_t L0 = S.chunk_off[d], L1 = S.chunk_off[d + 1];
-  uint32_t st = 0, bad = 0xFFFFFFFFu;
-  unsigned long long ntok = 0, nsent = 0, ntext = 0;
-  for (uint32_t L = L0; L < L1; L++) {
-    const DtkLanePlan pl = S.lane_plan[L];
-    const DtkLaneState en = S.lane_end[L];
-    if (pl.mode == PLAN_OFF) continue;  // behind the chain; judged at its PLAN_LAST lane
-    const DtkLaneCount c = S.lane_cnt[L];
-    st |= c.status; ntok += c.tok; nsent += c.sent; ntext += c.text;
-    if (pl.mode == PLAN_CHAINED) {
-      const DtkLaneState nx = S.lane_start[L + 1];
-      const bool same = en.p == nx.p && en.t == nx.t && ((en.flags ^ nx.flags) & cmp_mask) == 0 &&
-                        !(en.flags & LANE_F_DROPPED);
-      if (!same) { bad = L; break; }
-    } else {  // PLAN_LAST: must have run to EOF, and no later lane may claim a sync point
-      bool fine = en.p == 0xFFFFFFFFu;
-      for (uint32_t M = L + 1; fine && M < L1; M++) fine = S.lane_start[M].p == 0xFFFFFFFFu;
-      if (!fine) { bad = L; break; }
-    }
+// ---- repair rounds (a document whose chain broke is redone from its first bad lane on).
+// All per lane / per document / per block of positions, so that a long document repairs as fast
+// as a batch of short ones:
+//   k_redo_spread : the first bad lane started from a true state, so k_spec_fix made its end the
+//                   record of its successor.  Further down the document, a lane whose predecessor
+//                   arrived exactly but which itself missed its successor is in the same position
+//                   with high probability: its end becomes its successor's record too (speculation
+//                   again -- the next verification decides), so that one round repairs all isolated
+//                   misses of a document, not just the first.
+//   k_redo_reset  : per document, the counters and check words the round re-derives.
+//   k_redo_clear  : event bytes from the first redone position on.
+// then k_spec_link, k_spec_walk (redone lanes only), k_spec_verify (repaired documents only), k_spec_fix.
+__global__ __launch_bounds__(256) void k_redo_spread(DtkSpecArgs S) {
+  const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
+  if (L >= S.n_lanes) return;
+  const uint32_t d = S.lane_doc[L];
+  const uint32_t bad = S.redo_from[d];
+  if (bad == 0xFFFFFFFFu || L <= bad) return;
+  const uint32_t L1 = S.chunk_off[d + 1];
+  if (S.lane_end[bad].p == 0xFFFFFFFFu) {  // the first bad lane ran to EOF: no later lane has a sync point
+    S.lane_start[L].p = 0xFFFFFFFFu;
+    return;
   }
-  if (bad == 0xFFFFFFFFu) {
-    A.status[d] = st;
-    A.tok_cnt[d] = ntok; A.sent_cnt[d] = nsent; A.text_cnt[d] = ntext;
-    redo_out[d] = 0xFFFFFFFFu;
-  } else {
-    mark_redo(S, d, bad, redo_out, n_bad);
+  if (L + 1 >= L1) return;
+  DtkLaneState en = S.lane_end[L];
+  if (S.lane_plan[L].pad == 0u && S.lane_plan[L - 1].pad != 0u && L - 1 != bad &&
+      en.p != 0xFFFFFFFFu && !(en.flags & LANE_F_IDLE)) {  // (a lane that overshot dropped events: still a true end)
+    en.flags &= (LANE_F_SENT | LANE_F_TEXT | LANE_F_OK);
+    S.lane_start[L + 1] = en;
   }
 }
 
-// Zeroes both event arrays of every document that is being repaired, from the
-// start position of its first redone lane to the end (one wave per document).
-__global__ __launch_bounds__(WAVE) void k_spec_clear(DtkWalkArgs A, DtkSpecArgs S) {
-  const uint32_t d = blockIdx.x;
+__global__ __launch_bounds__(256) void k_redo_reset(DtkWalkArgs A, DtkSpecArgs S) {
+  const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d >= A.n_docs || S.redo_from[d] == 0xFFFFFFFFu) return;
+  A.tok_cnt[d] = 0; A.sent_cnt[d] = 0; A.text_cnt[d] = 0; A.status[d] = 0;
+  S.first_bad[d] = 0; S.fail_lane[d] = 0;
+  // the slot behind the last byte (k_redo_clear covers the positions that are bytes)
   const uint64_t off = A.doc_off[d];
   const uint32_t len = (uint32_t)(A.doc_off[d + 1] - off);
   const uint32_t from = S.lane_start[S.redo_from[d]].p;
-  uint8_t *a = A.evA + DTK_EV_BASE(off, d), *b = A.evB + DTK_EV_BASE(off, d);
-  for (uint32_t q = from + threadIdx.x; q <= len; q += WAVE) {
-    if (q > from) a[q] = 0;  // the closing byte at `from` belongs to the previous lane
-    b[q] = 0;
+  const uint64_t evb = DTK_EV_BASE(off, d);
+  if (len >= from) A.evB[evb + len] = 0;
+  if (len > from) A.evA[evb + len] = 0;
+}
+
+// one block per DTK_SYM_BLOCK_BYTES input bytes; blk_doc[b] = document of the block's first byte
+__global__ __launch_bounds__(256) void k_redo_clear(DtkWalkArgs A, DtkSpecArgs S, const uint32_t *blk_doc,
+                                                    uint64_t total) {
+  const uint64_t g0 = (uint64_t)blockIdx.x * DTK_SYM_BLOCK_BYTES;
+  const uint32_t d_lo = blk_doc[blockIdx.x];
+  const uint32_t d_hi = min(blk_doc[blockIdx.x + 1], A.n_docs - 1u);
+  for (uint32_t i = threadIdx.x; i < DTK_SYM_BLOCK_BYTES; i += blockDim.x) {
+    const uint64_t g = g0 + i;
+    if (g >= total) break;
+    const uint32_t d = doc_of(A.doc_off, d_lo, d_hi + 1u, g);
+    const uint32_t bad = S.redo_from[d];
+    if (bad == 0xFFFFFFFFu) continue;
+    const uint64_t off = A.doc_off[d];
+    const uint32_t p = (uint32_t)(g - off), from = S.lane_start[bad].p;
+    const uint64_t evb = DTK_EV_BASE(off, d);
+    if (p >= from) A.evB[evb + p] = 0;
+    if (p > from) A.evA[evb + p] = 0;  // the closing byte at `from` belongs to the lane before
   }
 }
 
@@ -1754,17 +1730,20 @@ extern "C" int dtk_launch_spec(const DtkTableDev *tab, const DtkWalkArgs *args, 
     case 4:
       hipLaunchKernelGGL(k_spec_fix, dim3(doc_blocks), dim3(256), 0, s, *args, *spec, redo_out, n_bad);
       return (int)hipGetLastError();
-    case 5:
-      hipLaunchKernelGGL(k_spec_clear, dim3(args->n_docs), dim3(WAVE), 0, s, *args, *spec);
-      return (int)hipGetLastError();
-    case 6:
-      hipLaunchKernelGGL(k_spec_plan, dim3(doc_blocks), dim3(256), 0, s, *args, *spec);
-      return (int)hipGetLastError();
-    case 7:
-      hipLaunchKernelGGL(k_spec_check, dim3(doc_blocks), dim3(256), 0, s, *args, *spec, cmp_mask, redo_out, n_bad);
+    case 5:  // repair round, before link / walk / verify / fix
+      hipLaunchKernelGGL(k_redo_spread, dim3(lane_blocks256), dim3(256), 0, s, *spec);
+      hipLaunchKernelGGL(k_redo_reset, dim3(doc_blocks), dim3(256), 0, s, *args, *spec);
       return (int)hipGetLastError();
   }
   return -1;
+}
+
+extern "C" int dtk_launch_redo_clear(const DtkWalkArgs *args, const DtkSpecArgs *spec, const uint32_t *blk_doc,
+                                     uint64_t total, void *stream) {
+  if (total == 0) return 0;
+  const uint32_t blocks = (uint32_t)((total + DTK_SYM_BLOCK_BYTES - 1) / DTK_SYM_BLOCK_BYTES);
+  hipLaunchKernelGGL(k_redo_clear, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *args, *spec, blk_doc, total);
+  return (int)hipGetLastError();
 }
 
 extern "C" int dtk_launch_compact(const DtkCompactArgs *args, int pass, void *stream) {
