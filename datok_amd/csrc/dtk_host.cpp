@@ -256,7 +256,9 @@ static int layout_matrix(dtk_model *m, const std::vector<uint32_t> &arr) {
     m->max_eps_chain = best;
   }
 
-  const bool wide = (N + 1) > 0x7FFFu;
+  // 32-bit cells for automata with 32767 states or more; DATOK_FORCE_WIDE=1 selects them for any
+  // model (no shipped model is that large: this is how the tests reach MatrixTrans<uint32_t>)
+  const bool wide = (N + 1) > 0x7FFFu || getenv("DATOK_FORCE_WIDE") != nullptr;
   const uint32_t stride = (uint32_t)((S + 7) & ~7ull);
   const size_t cells_total = (size_t)(N + 1) * stride;
   // 15-bit state ids: uint32 cells with fused epsilon+rune entries (MatrixFusedTrans);
