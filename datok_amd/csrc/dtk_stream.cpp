@@ -9,43 +9,66 @@
 #include "../../include/datok.hpp"
 
 namespace {
-// Borrowing view: the model stays owned by the caller.
-struct Borrowed {
-  datok::GpuTokenizer tok;
-  explicit Borrowed(const dtk_model *m) : tok(const_cast<dtk_model *>(m)) {}
+// One batch per calling thread, kept between calls (creating one costs a dozen device allocations and
+// a stream: milliseconds, far more than tokenizing a short string) and replaced when an input does
+// not fit.  dtk_transduce_release() frees it; so does the end of the thread.
+struct BatchCache {
+  dtk_batch *b = nullptr;
+  uint64_t cap = 0;
+  ~BatchCache() { dtk_batch_free(b); }
+  int get(uint64_t n, dtk_batch **out) {
+    if (!b || n > cap) {
+      dtk_batch_free(b);
+      b = nullptr;
+      cap = n < (64u << 10) ? (64u << 10) : n + n / 4;
+      int rc = dtk_batch_create(cap, 1, &b);
+      if (rc != DTK_OK) { b = nullptr; cap = 0; return rc; }
+    }
+    *out = b;
+    return DTK_OK;
+  }
+  void drop() { dtk_batch_free(b); b = nullptr; cap = 0; }
 };
+thread_local BatchCache g_cache;
+
+// set_input + run on the cached batch; a batch made for another device is replaced once
+int run_cached(const dtk_model *m, const uint8_t *text, size_t n, uint32_t flags, dtk_batch **bp) {
+  const uint64_t off[2] = {0, (uint64_t)n};
+  for (int attempt = 0; attempt < 2; attempt++) {
+    int rc = g_cache.get(n ? n : 1, bp);
+    if (rc != DTK_OK) return rc;
+    if ((rc = dtk_batch_set_input(*bp, text, off, 1)) != DTK_OK) return rc;
+    rc = dtk_batch_run(m, *bp, flags);
+    if (rc == DTK_E_ARG && attempt == 0) { g_cache.drop(); continue; }  // the model lives on another device
+    return rc;
+  }
+  return DTK_E_ARG;
+}
 }  // namespace
+
+extern "C" void dtk_transduce_release(void) { g_cache.drop(); }
 
 extern "C" int dtk_transduce(const dtk_model *m, const uint8_t *text, size_t n, uint32_t bits,
                              char **out, size_t *out_len, uint32_t *status) {
   if (!m || !out || (n && !text)) return DTK_E_ARG;
   *out = nullptr;
   dtk_batch *b = nullptr;
-  int rc = dtk_batch_create(n ? n : 1, 1, &b);
-  if (rc != DTK_OK) return rc;
-  const uint64_t off[2] = {0, (uint64_t)n};
   dtk_render_view v;
-  dtk_result_view r;
-  if ((rc = dtk_batch_set_input(b, text, off, 1)) != DTK_OK ||
-      (rc = dtk_batch_run(m, b, bits & DTK_NEWLINE_AFTER_EOT)) != DTK_OK ||
-      (rc = dtk_batch_render_host(b, bits, &v)) != DTK_OK ||
-      (rc = dtk_batch_result_device(b, &r)) != DTK_OK) {
-    dtk_batch_free(b);
+  int rc;
+  if ((rc = run_cached(m, text, n, bits & DTK_NEWLINE_AFTER_EOT, &b)) != DTK_OK ||
+      (rc = dtk_batch_render_host(b, bits, &v)) != DTK_OK)
     return rc;
-  }
   uint32_t st = 0;
-  rc = dtk_batch_status_host(b, &st, 1);
-  if (rc != DTK_OK) { dtk_batch_free(b); return rc; }
+  if ((rc = dtk_batch_status_host(b, &st, 1)) != DTK_OK) return rc;
   if (status) {
     // an empty text only breaks the position modes (token_writer.go:108,135,145)
     *status = st;
     if (!(bits & (DTK_TOKEN_POS | DTK_SENTENCE_POS))) *status &= ~(uint32_t)DTK_ST_EMPTY_TEXT;
   }
   char *p = (char *)malloc((size_t)v.total + 1);
-  if (!p) { dtk_batch_free(b); return DTK_E_NOMEM; }
+  if (!p) return DTK_E_NOMEM;
   memcpy(p, v.bytes, (size_t)v.total);
   p[v.total] = 0;
-  dtk_batch_free(b);
   *out = p;
   if (out_len) *out_len = (size_t)v.total;
   return DTK_OK;
@@ -56,16 +79,11 @@ extern "C" int dtk_transduce_replay(const dtk_model *m, const uint8_t *text, siz
   if (!m || !out || (n && !text)) return DTK_E_ARG;
   *out = nullptr;
   dtk_batch *b = nullptr;
-  int rc = dtk_batch_create(n ? n : 1, 1, &b);
-  if (rc != DTK_OK) return rc;
-  const uint64_t off[2] = {0, (uint64_t)n};
   dtk_result_view v;
-  if ((rc = dtk_batch_set_input(b, text, off, 1)) != DTK_OK ||
-      (rc = dtk_batch_run(m, b, bits & DTK_NEWLINE_AFTER_EOT)) != DTK_OK ||
-      (rc = dtk_batch_result_host(b, &v)) != DTK_OK) {
-    dtk_batch_free(b);
+  int rc;
+  if ((rc = run_cached(m, text, n, bits & DTK_NEWLINE_AFTER_EOT, &b)) != DTK_OK ||
+      (rc = dtk_batch_result_host(b, &v)) != DTK_OK)
     return rc;
-  }
   std::ostringstream os;
   auto tw = datok::NewTokenWriter(os, (datok::Bits)bits);
   datok::detail::replay(std::strcmp(dtk_model_type(m), "MATOK") == 0, text, n, v.events, v.events_open,
@@ -76,7 +94,6 @@ extern "C" int dtk_transduce_replay(const dtk_model *m, const uint8_t *text, siz
     *status = v.status[0];
     if (!(bits & (DTK_TOKEN_POS | DTK_SENTENCE_POS))) *status &= ~(uint32_t)DTK_ST_EMPTY_TEXT;
   }
-  dtk_batch_free(b);
   const std::string s = os.str();
   char *p = (char *)malloc(s.size() + 1);
   if (!p) return DTK_E_NOMEM;

@@ -242,6 +242,9 @@ int dtk_transduce(const dtk_model *m, const uint8_t *text, size_t n, uint32_t bi
                   char **out, size_t *out_len, uint32_t *status);
 int dtk_transduce_replay(const dtk_model *m, const uint8_t *text, size_t n, uint32_t bits,
                          char **out, size_t *out_len, uint32_t *status);
+/* Both keep one dtk_batch per calling thread between calls (sized for the largest input seen);
+ * this frees the calling thread's. */
+void dtk_transduce_release(void);
 void dtk_free(void *p);
 
 #ifdef __cplusplus
