@@ -23,7 +23,7 @@ EXPORTS = [
     "dtk_batch_set_profiling", "dtk_batch_stage_ms", "dtk_batch_set_chunking",
     "dtk_batch_result_device", "dtk_batch_result_host", "dtk_transduce", "dtk_free",
     "dtk_foma_to_matok", "dtk_transduce_replay", "dtk_batch_render_device", "dtk_batch_render_host",
-    "dtk_batch_status_host", "dtk_transduce_release",
+    "dtk_batch_status_host", "dtk_transduce_release", "dtk_transduce_result",
 ]
 
 
@@ -121,6 +121,7 @@ def lib():
     L.dtk_transduce.argtypes = [vp, C.c_char_p, sz, u32, C.POINTER(vp), C.POINTER(sz), C.POINTER(u32)]
     L.dtk_transduce_replay.argtypes = L.dtk_transduce.argtypes
     L.dtk_transduce_release.restype = None
+    L.dtk_transduce_result.argtypes = [vp, C.c_char_p, sz, u32, C.POINTER(ResultView)]
     L.dtk_batch_render_device.argtypes = [vp, u32, C.POINTER(RenderView)]
     L.dtk_batch_render_host.argtypes = [vp, u32, C.POINTER(RenderView)]
     L.dtk_batch_status_host.argtypes = [vp, vp, u32]

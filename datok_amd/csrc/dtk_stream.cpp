@@ -48,6 +48,17 @@ int run_cached(const dtk_model *m, const uint8_t *text, size_t n, uint32_t flags
 
 extern "C" void dtk_transduce_release(void) { g_cache.drop(); }
 
+// The walk of ONE stream on the calling thread's cached batch; the host view stays valid until this
+// thread's next dtk_transduce* call.  What a TransduceTokenWriter with a custom writer replays from.
+extern "C" int dtk_transduce_result(const dtk_model *m, const uint8_t *text, size_t n, uint32_t flags,
+                                    dtk_result_view *view) {
+  if (!m || !view || (n && !text)) return DTK_E_ARG;
+  dtk_batch *b = nullptr;
+  int rc = run_cached(m, text, n, flags & DTK_NEWLINE_AFTER_EOT, &b);
+  if (rc != DTK_OK) return rc;
+  return dtk_batch_result_host(b, view);
+}
+
 extern "C" int dtk_transduce(const dtk_model *m, const uint8_t *text, size_t n, uint32_t bits,
                              char **out, size_t *out_len, uint32_t *status) {
   if (!m || !out || (n && !text)) return DTK_E_ARG;

@@ -191,16 +191,19 @@ class Tokenizer:
         text = r.read() if hasattr(r, "read") else bytes(r)
         if isinstance(text, str):
             text = text.encode("utf-8")
-        try:
-            with Batch(max(len(text), 1), 1) as b:
-                b.set_input(np.frombuffer(text, dtype=np.uint8), np.array([0, len(text)], dtype=np.uint64))
-                b.run(self, 0)
-                res = b.result()
-        except _lib.DatokGpuError as e:        # the reference returns false
-            print("datok_amd:", e, file=sys.stderr)
+        v = ResultView()   # dtk_transduce_result: the library's per-thread batch, host pointers
+        rc = lib().dtk_transduce_result(self._h, text, len(text), 0, C.byref(v))
+        if rc != _lib.OK:                      # the reference returns false
+            print("datok_amd:", _lib.DatokGpuError(rc, "dtk_transduce_result"), file=sys.stderr)
             return False
-        self.last_status = int(res.status[0])
-        replay(self.type() == "MATOK", text, res.events, res.tok_bstart, tw)
+        n_ev = len(text) + 1
+        ntok = int(np.frombuffer((C.c_char * 16).from_address(v.tok_off), dtype=np.uint64)[1])
+
+        def arr(ptr, n, dt):
+            return np.frombuffer((C.c_char * (n * np.dtype(dt).itemsize)).from_address(ptr), dtype=dt) if n else np.zeros(0, dt)
+        events = (arr(v.events, n_ev, np.uint8) & np.uint8(7)) | arr(v.events_open, n_ev, np.uint8)
+        self.last_status = int(arr(v.status, 1, np.uint32)[0])
+        replay(self.type() == "MATOK", text, events, arr(v.tok_bstart, ntok, np.uint32), tw)
         tw.Flush()                              # `defer w.Flush()`, matrix.go:374
         return True
 

@@ -274,17 +274,12 @@ class GpuTokenizer final : public Tokenizer {
   }
 
   bool TransduceBytes(const uint8_t *text, size_t n, TokenWriter &w) {
-    dtk_batch *b = nullptr;
-    if (dtk_batch_create(n ? n : 1, 1, &b) != DTK_OK) return false;
-    const uint64_t off[2] = {0, (uint64_t)n};
-    dtk_result_view v;
-    bool ok = dtk_batch_set_input(b, text, off, 1) == DTK_OK && dtk_batch_run(m_, b, 0) == DTK_OK &&
-              dtk_batch_result_host(b, &v) == DTK_OK;
+    dtk_result_view v;  // on the calling thread's cached batch
+    const bool ok = dtk_transduce_result(m_, text, n, 0, &v) == DTK_OK;
     if (ok) {
       last_status_ = v.status[0];
       detail::replay(Type() == "MATOK", text, n, v.events, v.events_open, v.tok_bstart, w);
     }
-    dtk_batch_free(b);
     return ok;
   }
   uint32_t last_status() const { return last_status_; }

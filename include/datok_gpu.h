@@ -245,6 +245,9 @@ int dtk_transduce_replay(const dtk_model *m, const uint8_t *text, size_t n, uint
 /* Both keep one dtk_batch per calling thread between calls (sized for the largest input seen);
  * this frees the calling thread's. */
 void dtk_transduce_release(void);
+/* The walk of one stream on that per-thread batch: host pointers, valid until the thread's next
+ * dtk_transduce* call -- what TransduceTokenWriter with a custom writer replays from. */
+int dtk_transduce_result(const dtk_model *m, const uint8_t *text, size_t n, uint32_t flags, dtk_result_view *view);
 void dtk_free(void *p);
 
 #ifdef __cplusplus
