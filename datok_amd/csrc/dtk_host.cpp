@@ -984,7 +984,7 @@ static int plan_lanes(dtk_batch *b) {
       if (p) HIP_TRY(hipFree(p));
     b->d_seg_tab = nullptr; b->d_seg_sum = nullptr; b->d_seg_in = nullptr;
     const uint64_t cap = (uint64_t)ns + ns / 8 + 64;
-    HIP_TRY(hipMalloc((void **)&b->d_seg_tab, (3 * cap + b->max_docs + 1) * 4));
+    HIP_TRY(hipMalloc((void **)&b->d_seg_tab, (3 * cap + 2 * ((uint64_t)b->max_docs + 1)) * 4));
     HIP_TRY(hipMalloc((void **)&b->d_seg_sum, cap * sizeof(DtkSegSum)));
     HIP_TRY(hipMalloc((void **)&b->d_seg_in, cap * sizeof(DtkSegIn)));
     b->seg_cap = (uint32_t)cap;
@@ -1043,13 +1043,14 @@ static int launch_compact2(dtk_batch *b) {
   a.tok_sbefore = ro ? nullptr : b->d_sbefore; a.text_s_end = ro ? nullptr : b->d_ts_end;
   a.doc_ns = ro ? nullptr : b->d_doc_ns;
   a.tok_cap = b->tok_cap; a.sent_cap = b->sent_cap; a.text_cap = b->text_cap;
-  // a document of many lanes is compacted by one wave per DTK_SEG_LANES lanes (matrix walk: the
-  // double array keeps its window over an EOT, datok.go:1019-1030, so its carries are not closed-form)
-  const bool seg = b->chunk != 0 && b->long_docs && b->last_model && b->last_model->kind == DTK_KIND_MATRIX;
+  // a document of many lanes is compacted by one wave per DTK_SEG_LANES lanes (a double-array document
+  // with an EOT inside stays sequential: k_seg_scan decides)
+  const bool seg = b->chunk != 0 && b->long_docs;
   a.seg_doc = seg ? b->d_seg_tab : nullptr;
   a.seg_lane0 = b->d_seg_tab + b->seg_cap; a.seg_nl = b->d_seg_tab + 2 * (size_t)b->seg_cap;
   a.n_segs = b->n_segs; a.chunk_off = b->d_chunk_off; a.lane_start = b->d_lane_start; a.lane_cnt = b->d_lane_cnt;
   a.seg_sum = b->d_seg_sum; a.seg_in = b->d_seg_in;
+  a.doc_seq = b->d_seg_tab + 3 * (size_t)b->seg_cap + b->max_docs + 1;
   b->last_args = a;
   if (seg && dtk_launch_seg_prepare(&a, b->d_seg_tab + 3 * (size_t)b->seg_cap, b->stream))
     return hip_fail(hipGetLastError(), "segment carries");

@@ -172,6 +172,7 @@ struct DtkCompactArgs {
   const struct DtkLaneCount *lane_cnt;
   struct DtkSegSum *seg_sum;              // k_seg_sum: what a segment adds
   struct DtkSegIn *seg_in;                // k_seg_scan: the carries a segment starts with
+  uint32_t *doc_seq;                      // k_seg_scan: 1 = this long document must be compacted sequentially
 };
 
 #define DTK_SEG_LANES 64u

@@ -1239,10 +1239,15 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
   SegRange sr{d, 0u, len, true, true};
   if (seg_mode) {
     if (!seg_range(A, blockIdx.x, len, sr)) return;
+    if (A.chunk_off[d + 1] - A.chunk_off[d] > DTK_SEG_LANES && A.doc_seq[d]) {  // sequential after all
+      if (!sr.first) return;
+      sr.p1 = len; sr.last = true;
+    }
     if (!sr.first) {
       // Everything the sequential pass would carry into position p0 (a sync point of the walk: the
       // window was rewound there) follows from the totals of the lanes before it and from the last
-      // EOT TextEnd before it (k_seg_scan).  Matrix walk only (matrix.go:601 rewinds at EOT).
+      // EOT TextEnd before it (k_seg_scan).  (The matrix rewinds at an EOT, matrix.go:601; a double-array
+      // document with an EOT does not get here.)
       const DtkSegIn in = A.seg_in[blockIdx.x];
       cR = in.runes; cTE = in.tok; cNE = in.text; cNSev = in.sev; cNSent = in.sent;
       cHaveE = in.e_pos != 0xFFFFFFFFu;
@@ -1574,6 +1579,7 @@ __global__ __launch_bounds__(WAVE) void k_seg_scan(DtkCompactArgs A, const uint3
   const uint32_t s0 = doc_seg0[d], s1 = doc_seg0[d + 1];
   if (s1 - s0 <= 1u) return;
   const uint32_t lane = lane_id();
+  bool any_e = false;  // an EOT TextEnd somewhere in the document
   uint32_t bt = 0, bs = 0, bx = 0, bv = 0, br = 0;        // running totals before the current group of 64
   uint32_t ce_pos = 0xFFFFFFFFu, ce_tok = 0, ce_runes = 0;  // last EOT TextEnd so far (absolute)
   for (uint32_t g = s0; g < s1; g += WAVE) {
@@ -1597,9 +1603,13 @@ __global__ __launch_bounds__(WAVE) void k_seg_scan(DtkCompactArgs A, const uint3
     if (mE) {
       const int jl = highest(mE);
       ce_pos = __shfl(v.e_pos, jl); ce_tok = __shfl(bt + et + v.e_tok, jl); ce_runes = __shfl(br + er + v.e_runes, jl);
+      any_e = true;
     }
     bt += tt; bs += ts; bx += tx; bv += tv; br += tr;
   }
+  // The double array keeps its window over an EOT (datok.go:1019-1030): its carries are only
+  // closed-form in documents without one; the others are compacted by their first segment alone.
+  if (lane == 0) A.doc_seq[d] = (A.kind != DTK_KIND_MATRIX && any_e) ? 1u : 0u;
 }
 
 

@@ -64,8 +64,10 @@ for seed in range(first, first + n_seeds):
              ("tokenizer_de.datok", corpus.german_docs(128, 4096, seed=seed + 7)),
              (str(rng.choice(list(models))), random_docs(rng, 300)),
              # a few long documents full of EOT texts, blanks and odd bytes: many compaction segments
-             (str(rng.choice(["tokenizer_de.matok", "tokenizer_en.matok", "clitic_test.matok"])),
-              long_docs(rng, int(rng.integers(1, 4))))]
+             (str(rng.choice(["tokenizer_de.matok", "tokenizer_en.matok", "clitic_test.matok", "tokenizer_de.datok"])),
+              long_docs(rng, int(rng.integers(1, 4)))),
+             # the double array on long documents without EOT (segments) 
+             ("tokenizer_de.datok", corpus.german_docs(int(rng.integers(2, 6)), int(rng.choice([20000, 70000])), seed=seed + 3))]
     for name, (text, off) in cases:
         tok, om = models[name]
         chunk, warm = [(None, 48), (0, 48), (64, 48), (128, 16), (256, 48), (48, 0), (1024, 48)][int(rng.integers(0, 7))]

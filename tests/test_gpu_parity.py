@@ -507,3 +507,22 @@ def test_long_documents_with_eot_texts_in_segments(gpu, oracle_models, model, fl
                 exp, est = om.transduce(docs[d], bits | flags)
                 if est == 0:
                     assert data[int(o[d]):int(o[d + 1])] == exp, (model, flags, chunk, bits, d)
+
+
+def test_double_array_long_documents(gpu, oracle_models):
+    """The double array's long documents: in segments when they hold no EOT, sequentially otherwise
+    (datok.go:1019-1030 keeps the window over an EOT, so the segment carries are not closed-form)."""
+    from datok_amd import corpus, ST_IRREGULAR
+    text, off = corpus.german_docs(6, 60000, seed=41)
+    raw = bytearray(text.tobytes())
+    for p in (70000, 70001, 130000, 200000):     # documents 1, 2 and 3 get EOTs; 0, 4, 5 stay clean
+        raw[p] = 4
+    text = np.frombuffer(bytes(raw), dtype=np.uint8)
+    res, tot = run_batch(gpu("tokenizer_de.datok"), text, off, NEWLINE_AFTER_EOT, chunk=128)
+    assert tot["n_lanes"] > 64 * 6
+    keep = [d for d in range(6) if not (res.status[d] & ST_IRREGULAR)]
+    assert set(keep) >= {0, 4, 5}
+    assert_batch_equals_oracle(oracle_models("tokenizer_de.datok"), res, text, off, NEWLINE_AFTER_EOT, docs=keep)
+    a, _ = run_batch(gpu("tokenizer_de.matok"), text, off, NEWLINE_AFTER_EOT, chunk=128)
+    for d in (0, 4, 5):   # without EOT both encodings give the same offsets
+        assert np.array_equal(a.doc(d)["tok_rstart"], res.doc(d)["tok_rstart"])
