@@ -19,6 +19,9 @@
 #define DTK_SYM_W_SHIFT 11
 #define DTK_SYM_CLS_SHIFT 13
 #define DTK_SYM_START 0x8000u
+// the lean walk's per-lane window of the symbol stream in LDS: entries, and u16 per row (72 B)
+#define DTK_WIN 32u
+#define DTK_WIN_ROW 36u
 
 // ---- event byte (one per byte position 0..len of every document); bit order is
 // the order in which the reference fires the calls at one cursor position: the

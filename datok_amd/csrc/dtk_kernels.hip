@@ -664,11 +664,30 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
 // lane state in plain integers, and one guarded block for everything that happens less than
 // once per token (hard fail, EOT, end of input, end of the chunk, the window limit).
 // Behaviour is identical to walk_lane<MatrixFusedTrans, true, MODE> for such models.
+//
+// Symbol stream: every lane keeps a window of DTK_WIN entries of its own stretch of the stream in
+// LDS (its private row; rows are 72 B apart so that the 64 lanes start in different banks).  The
+// window is filled with four 16-byte loads per lane and read with one ds_read_u16 per iteration;
+// when any lane of the wave leaves its window all lanes re-base theirs (a wave-uniform branch,
+// once per ~28 iterations).  Read straight from memory in 8-byte groups, the lanes' 64 stream
+// lines and the table lines evict each other from the 32 KiB L1 and every group load goes to L2.
+typedef uint2 __attribute__((may_alias)) dtk_u2a;
+typedef uint16_t __attribute__((may_alias)) dtk_u16a;
+__device__ __forceinline__ void win_fill(dtk_u16a *row, const uint16_t *__restrict__ aligned, uint32_t wbase) {
+  const uint4 *__restrict__ g = reinterpret_cast<const uint4 *>(aligned + wbase);
+  const uint4 v0 = g[0], v1 = g[1], v2 = g[2], v3 = g[3];
+  dtk_u2a *r = reinterpret_cast<dtk_u2a *>(row);
+  r[0] = make_uint2(v0.x, v0.y); r[1] = make_uint2(v0.z, v0.w);
+  r[2] = make_uint2(v1.x, v1.y); r[3] = make_uint2(v1.z, v1.w);
+  r[4] = make_uint2(v2.x, v2.y); r[5] = make_uint2(v2.z, v2.w);
+  r[6] = make_uint2(v3.x, v3.y); r[7] = make_uint2(v3.z, v3.w);
+}
+
 template <int MODE>
 __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uint16_t *__restrict__ sym_base,
                                            uint64_t off, uint32_t len, DtkLaneState init, uint32_t stop_pos,
                                            EventSink &sink, uint32_t epsilon, uint32_t cap, DtkLaneState &fin,
-                                           uint32_t &st_out, uint32_t &steps_out) {
+                                           uint32_t &st_out, uint32_t &steps_out, uint16_t *win_row) {
   const uint16_t *__restrict__ s = sym_base + off;
   const uint32_t *__restrict__ tab = tr.tab;
   const uint32_t stride = tr.stride, n_eps = tr.n_eps;
@@ -684,17 +703,13 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
   uint32_t st = 0, it = 0;
   fin.p = 0xFFFFFFFFu; fin.t = 0; fin.aux = 0; fin.flags = 0;  // p stays "ran to EOF" unless the lane stops
   bool done = false;
-  // Symbol stream in aligned groups of 4 entries (8-byte loads).  q_cur is the group of the rune
-  // this iteration reads, q_next the one behind it.  Refills are issued one iteration early (for
-  // the position the lane reaches if its rune is consumed) and land in ld_a / ld_b; they are
-  // moved into q_cur / q_next at the top of the next iteration, i.e. after that iteration's
-  // cell load has been waited for anyway -- a refill never stalls the wave by itself.
-  const uint32_t o3 = (uint32_t)(off & 3u);
-  const uint64_t *__restrict__ sq = reinterpret_cast<const uint64_t *>(sym_base + (off - o3));
-  uint32_t grp = (p + o3) >> 2;
-  uint64_t q_cur = sq[grp], q_next = sq[grp + 1u];
-  uint64_t ld_a = 0, ld_b = 0;
-  uint32_t pend = 0;  // 1: ld_b -> q_next;  2: also ld_a -> q_cur
+  // the lane's window of the symbol stream: entries (pos + o7) in [wbase, wbase + DTK_WIN)
+  dtk_u16a *row = reinterpret_cast<dtk_u16a *>(win_row);
+  const uint32_t o7 = (uint32_t)(off & 7u);
+  const uint16_t *__restrict__ aligned = sym_base + (off - o7);
+  uint32_t wbase = (p + o7) & ~7u;
+  win_fill(row, aligned, wbase);
+  uint32_t e_next = row[(p + o7) - wbase];
 
   // reader at EOF: the drain of matrix.go:650-668 (checked before every rune)
 #define DTK_EOF_DRAIN()                                              \
@@ -710,33 +725,23 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
   DTK_EOF_DRAIN()
   while (!done) {
     it++;
-    if (pend) {
-      q_next = ld_b;
-      q_cur = pend == 2u ? ld_a : q_cur;
-      pend = 0;
-    }
     const bool r = retry != 0;
-    // the rune at p (an epsilon iteration reads none: the extracted entry is then not used)
-    const uint32_t e = (uint32_t)(q_cur >> (((p + o3) & 3u) * 16u));
+    // the rune at p (an epsilon iteration reads none: the entry is then not used)
+    const uint32_t e = e_next;
     const uint32_t a = r ? epsilon : (e & DTK_SYM_MASK);
     const uint32_t x = tab[(size_t)t * stride + a];
-    // while the cell is on its way: the group of the position the next rune is read from (behind
+    // while the cell is on its way: the entry of the position the next rune is read from (behind
     // this rune; after a backtrack the epsilon iteration, which reads no rune, does this for the
     // position it returns to)
     const uint32_t pn = r ? p : p + ((e >> DTK_SYM_W_SHIFT) & 3u) + 1u;
     {
-      const uint32_t g = (pn + o3) >> 2;
-      if (g != grp) {
-        if (g == grp + 1u) {
-          q_cur = q_next;
-          pend = 1;
-        } else {
-          ld_a = sq[g];
-          pend = 2;
-        }
-        ld_b = sq[g + 1u];
-        grp = g;
+      uint32_t iw = pn + o7 - wbase;
+      if (__builtin_amdgcn_ballot_w64(iw >= DTK_WIN) != 0ull) {  // also a backtrack to before the window
+        wbase = (pn + o7) & ~7u;
+        win_fill(row, aligned, wbase);
+        iw = (pn + o7) & 7u;
       }
+      e_next = row[iw];
     }
     hi = max(hi, pn);                                   // matrix.go:388-408
     const bool he = !r && t <= n_eps;                   // matrix.go:442-454
@@ -783,8 +788,10 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
         if (r) { st |= ST_BAD_MODEL; done = true; }
         else {
           if (p <= tp) { p = pn; }  // matrix.go:515-516
-          else {  // the rune is read again: its group, now
-            grp = (p + o3) >> 2; q_cur = sq[grp]; q_next = sq[grp + 1u]; pend = 0;
+          else {  // the rune is read again
+            uint32_t iw = p + o7 - wbase;
+            if (iw >= DTK_WIN) { wbase = (p + o7) & ~7u; win_fill(row, aligned, wbase); iw = (p + o7) & 7u; }
+            e_next = row[iw];
           }
           if (MODE != MODE_START) sink.template token<true>(tp, p, ((F ^ 4u) & 7u) != 0);
           F = 12u;
@@ -836,9 +843,10 @@ template <typename TRANS, bool IS_MATRIX, int MODE>
 __device__ __forceinline__ void walk_any(const TRANS &tr, const uint16_t *__restrict__ sym_base, uint64_t off,
                                          uint32_t len, DtkLaneState init, uint32_t stop_pos, EventSink &sink,
                                          uint32_t epsilon, uint32_t unknown, uint32_t identity, uint32_t cap,
-                                         DtkLaneState &fin, uint32_t &st_out, uint32_t &steps_out) {
+                                         DtkLaneState &fin, uint32_t &st_out, uint32_t &steps_out,
+                                         uint16_t *win_row) {
   if constexpr (TRANS::LEAN)
-    walk_fused<MODE>(tr, sym_base, off, len, init, stop_pos, sink, epsilon, cap, fin, st_out, steps_out);
+    walk_fused<MODE>(tr, sym_base, off, len, init, stop_pos, sink, epsilon, cap, fin, st_out, steps_out, win_row);
   else
     walk_lane<TRANS, IS_MATRIX, MODE>(tr, sym_base, off, len, init, stop_pos, sink, epsilon, unknown, identity, cap,
                                       fin, st_out, steps_out);
@@ -860,6 +868,8 @@ __device__ __forceinline__ void add_steps(unsigned long long *counter, uint32_t 
 template <typename TRANS, bool IS_MATRIX>
 __global__ __launch_bounds__(WAVE) void k_walk_doc(TRANS tr, DtkWalkArgs A, uint32_t epsilon,
                                                    uint32_t unknown, uint32_t identity) {
+  __shared__ uint16_t s_win[TRANS::LEAN ? WAVE * DTK_WIN_ROW : 8];
+  uint16_t *win_row = s_win + (TRANS::LEAN ? threadIdx.x * DTK_WIN_ROW : 0u);
   const uint32_t d = blockIdx.x * WAVE + threadIdx.x;
   uint32_t steps = 0;
   if (d < A.n_docs) {
@@ -871,7 +881,7 @@ __global__ __launch_bounds__(WAVE) void k_walk_doc(TRANS tr, DtkWalkArgs A, uint
     DtkLaneState init{0u, tr.start_state(), tr.start_aux(), 0u}, fin;
     uint32_t st;
     walk_any<TRANS, IS_MATRIX, MODE_DOC>(tr, A.sym, off, len, init, 0u, sink, epsilon, unknown,
-                                          identity, step_cap(A.step_factor, len), fin, st, steps);
+                                          identity, step_cap(A.step_factor, len), fin, st, steps, win_row);
     A.status[d] = st | sink.st;
     A.tok_cnt[d] = sink.c_tok; A.sent_cnt[d] = sink.c_sent; A.text_cnt[d] = sink.c_text;
   }
@@ -898,6 +908,8 @@ template <typename TRANS, bool IS_MATRIX>
 __global__ __launch_bounds__(WAVE) void k_spec_start(TRANS tr, DtkWalkArgs A, DtkSpecArgs S,
                                                      uint32_t epsilon, uint32_t unknown,
                                                      uint32_t identity) {
+  __shared__ uint16_t s_win[TRANS::LEAN ? WAVE * DTK_WIN_ROW : 8];
+  uint16_t *win_row = s_win + (TRANS::LEAN ? threadIdx.x * DTK_WIN_ROW : 0u);
   const uint32_t L = blockIdx.x * WAVE + threadIdx.x;
   uint32_t steps = 0;
   if (L < S.n_lanes) {
@@ -936,7 +948,7 @@ __global__ __launch_bounds__(WAVE) void k_spec_start(TRANS tr, DtkWalkArgs A, Dt
           sink.init(nullptr, nullptr, 0u, 0u);
           uint32_t st;
           walk_any<TRANS, IS_MATRIX, MODE_START>(tr, A.sym, off, len, init, kc, sink, epsilon, unknown,
-                                                  identity, step_cap(A.step_factor, len), rec, st, steps);
+                                                  identity, step_cap(A.step_factor, len), rec, st, steps, win_row);
         }
         // sp == 0: the walk from the true initial state; its first sync point at/after kc
         else {
@@ -944,7 +956,7 @@ __global__ __launch_bounds__(WAVE) void k_spec_start(TRANS tr, DtkWalkArgs A, Dt
           sink.init(nullptr, nullptr, 0u, 0u);
           uint32_t st;
           walk_any<TRANS, IS_MATRIX, MODE_START>(tr, A.sym, off, len, rec, kc, sink, epsilon, unknown,
-                                                  identity, step_cap(A.step_factor, len), rec, st, steps);
+                                                  identity, step_cap(A.step_factor, len), rec, st, steps, win_row);
         }
       }
       S.lane_start[L] = rec;
@@ -996,6 +1008,8 @@ template <typename TRANS, bool IS_MATRIX>
 __global__ __launch_bounds__(WAVE) void k_spec_walk(TRANS tr, DtkWalkArgs A, DtkSpecArgs S,
                                                     uint32_t epsilon, uint32_t unknown,
                                                     uint32_t identity) {
+  __shared__ uint16_t s_win[TRANS::LEAN ? WAVE * DTK_WIN_ROW : 8];
+  uint16_t *win_row = s_win + (TRANS::LEAN ? threadIdx.x * DTK_WIN_ROW : 0u);
   const uint32_t L = blockIdx.x * WAVE + threadIdx.x;
   uint32_t steps = 0;
   if (L < S.n_lanes) {
@@ -1014,7 +1028,7 @@ __global__ __launch_bounds__(WAVE) void k_spec_walk(TRANS tr, DtkWalkArgs A, Dtk
         sink.init(A.evA + evb, A.evB + evb, init.p, pl.wend);
         uint32_t st = 0;
         walk_any<TRANS, IS_MATRIX, MODE_CHUNK>(tr, A.sym, off, len, init, pl.stop, sink, epsilon, unknown,
-                                                identity, step_cap(A.step_factor, len), fin, st, steps);
+                                                identity, step_cap(A.step_factor, len), fin, st, steps, win_row);
         if (sink.dropped) fin.flags |= LANE_F_DROPPED;
         cnt.tok = sink.c_tok; cnt.sent = sink.c_sent; cnt.text = sink.c_text; cnt.status = st | sink.st;
         cnt.sev = sink.c_sev; cnt.e_pos = sink.e_pos; cnt.e_tok = sink.e_tok;
