@@ -22,6 +22,11 @@
 // the lean walk's per-lane window of the symbol stream in LDS: entries, and u16 per row (72 B)
 #define DTK_WIN 32u
 #define DTK_WIN_ROW 36u
+// the lean walk's per-lane list of event bytes in LDS: entries, fill level at which the wave writes
+// its lists out, dwords per row (odd: the rows of the 64 lanes start in different banks)
+#define DTK_ELIST 16u
+#define DTK_ELIST_HIGH 12u
+#define DTK_ELIST_ROW 17u
 
 // ---- event byte (one per byte position 0..len of every document); bit order is
 // the order in which the reference fires the calls at one cursor position: the

@@ -373,9 +373,19 @@ struct DaTrans {
 //   opening: lo <= pos < hi      closing: lo < pos <= hi
 // (whole document: lo = 0, hi = 0xFFFFFFFF); an event outside is dropped and
 // remembered, the check pass then knows the lane left its window.
+//
+// The lean walk does not store its event bytes one by one: a single-byte store every few
+// iterations from each of 64 lanes, to 64 different lines, keeps more dirty lines in flight than
+// the L2 holds (measured: without the stores the walk of a large batch takes 37 % less time).
+// The lane appends (position, array, byte) to a private list in LDS instead (elist, DTK_ELIST
+// entries of  (pos - lo) << 9 | array << 8 | byte ); the wave writes its lists out together when
+// one of them runs full and at the end, so that the stores to one line arrive back to back.
 struct EventSink {
-  uint8_t *evA, *evB;  // closing / opening, index = position in the document
+  uint8_t *evA;        // closing bytes, index = position in the document
+  uint64_t dB;         // the opening bytes are at evA + dB
   uint32_t lo, hi;     // window
+  uint32_t *elist;     // the lane's list in LDS (nullptr: plain stores)
+  uint32_t ecount;
   uint32_t last_s_p, s_bits;      // position / byte of the last opening SentenceEnd
   uint32_t last_eot_p, eot_bits;  // position / byte of the last EOT pair (double array merge)
   uint32_t st;
@@ -385,11 +395,32 @@ struct EventSink {
   uint32_t c_tok, c_sent, c_text;
   uint32_t c_sev;         // SentenceEnd calls (all of them, also where the reference would panic)
   uint32_t e_pos, e_tok;  // the last EOT TextEnd of this lane: position, Token calls before it
-  __device__ __forceinline__ void init(uint8_t *a, uint8_t *b, uint32_t wlo, uint32_t whi) {
-    evA = a; evB = b; lo = wlo; hi = whi;
+  __device__ __forceinline__ void init(uint8_t *a, uint8_t *b, uint32_t wlo, uint32_t whi,
+                                       uint32_t *list = nullptr) {
+    evA = a; dB = (uint64_t)(b - a); lo = wlo; hi = whi; elist = list; ecount = 0;
     last_s_p = last_eot_p = 0xFFFFFFFFu; s_bits = eot_bits = 0; st = 0; dropped = 0;
     c_tok = c_sent = c_text = 0;
     c_sev = 0; e_pos = 0xFFFFFFFFu; e_tok = 0;
+  }
+  // writes the listed bytes; lanes of a wave call it together (the loop runs to the longest list)
+  __device__ __forceinline__ void flush() {
+#pragma unroll 1
+    for (uint32_t i = 0; i < ecount; i++) {
+      const uint32_t e = elist[i];
+      evA[(uint64_t)lo + (e >> 9) + ((e & 256u) ? dB : 0ull)] = (uint8_t)e;
+    }
+    ecount = 0;
+  }
+  // arr: 0 closing, 1 opening;  pos is inside the window (>= lo).  The walk writes its lists out
+  // before one can run full (at most 3 bytes per iteration); the plain store is for lanes without
+  // a list and for windows of 8 MiB and more.
+  __device__ __forceinline__ void put(uint32_t arr, uint32_t pos, uint32_t v) {
+    const uint32_t rel = pos - lo;
+    if (elist != nullptr && rel < (1u << 23) && ecount < DTK_ELIST) {
+      elist[ecount++] = (rel << 9) | (arr << 8) | (v & 255u);
+      return;
+    }
+    evA[(uint64_t)pos + (arr ? dB : 0ull)] = (uint8_t)v;
   }
   __device__ __forceinline__ bool in_closing(uint32_t p) const { return p > lo && p <= hi; }
   __device__ __forceinline__ bool in_opening(uint32_t p) const { return p >= lo && p < hi; }
@@ -407,8 +438,8 @@ struct EventSink {
     // more additionally marks its start in the opening byte of its first position (a SentenceEnd
     // may have fired at that cursor before: same byte, stored by this lane)
     const uint32_t bl = p - tp;
-    evA[p] = (uint8_t)(bits | ((bl < EV_LEN_LONG ? bl : EV_LEN_LONG) << EV_LEN_SHIFT));
-    if (bl >= EV_LEN_LONG) evB[tp] = (uint8_t)(EV_TOK_START | (tp == last_s_p ? s_bits : 0u));
+    put(0u, p, bits | ((bl < EV_LEN_LONG ? bl : EV_LEN_LONG) << EV_LEN_SHIFT));
+    if (bl >= EV_LEN_LONG) put(1u, tp, EV_TOK_START | (tp == last_s_p ? s_bits : 0u));
   }
   // SentenceEnd? + TextEnd fired by an EOT rune -- matrix.go:593-600
   // has_tok: the current text has a token (else the reference panics in position modes)
@@ -422,7 +453,7 @@ struct EventSink {
     if (!IS_MATRIX && p == last_eot_p) st |= ST_IRREGULAR;  // the same EOT consumed twice
     const uint32_t bits = EV_E_EOT | (with_sentence ? EV_S_EOT : 0u);
     if (!IS_MATRIX) { last_eot_p = p; eot_bits = bits; }
-    evA[p] = (uint8_t)bits;
+    put(0u, p, bits);
   }
   // SentenceEnd from an epsilon arc on an empty token -- matrix.go:574-575
   __device__ __forceinline__ void sentence(uint32_t p, bool has_tok) {
@@ -436,7 +467,7 @@ struct EventSink {
       last_s_p = p;
       s_bits = EV_S_EPS;
     }
-    evB[p] = (uint8_t)s_bits;
+    put(1u, p, s_bits);
   }
   // final SentenceEnd / TextEnd -- matrix.go:683-691
   __device__ __forceinline__ void tail(uint32_t p, bool sentence_end, bool text_end, bool has_tok) {
@@ -446,7 +477,7 @@ struct EventSink {
     if (!text_end) c_text++;
     c_sev += sentence_end ? 0u : 1u;
     if (has_tok) c_sent += sentence_end ? 0u : 1u; else st |= ST_EMPTY_TEXT;
-    evB[p] = (uint8_t)(bits | (p == last_s_p ? s_bits : 0u));
+    put(1u, p, bits | (p == last_s_p ? s_bits : 0u));
   }
 };
 
@@ -821,6 +852,8 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
       if (it > cap && !done) { st |= ST_STEP_LIMIT; done = true; }
     }
     if (!done) { DTK_EOF_DRAIN() }
+    // one list of the wave is nearly full: all lanes write theirs out
+    if (MODE != MODE_START && __builtin_amdgcn_ballot_w64(sink.ecount >= DTK_ELIST_HIGH) != 0ull) sink.flush();
   }
 #undef DTK_EOF_DRAIN
 
@@ -834,6 +867,7 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
       sink.tail(p, (F & 1u) != 0, (F & 2u) != 0, (F & 8u) != 0);  // matrix.go:683-691
     }
   }
+  if (MODE != MODE_START) sink.flush();
   st_out = st;
   steps_out = it;  // lookups
 }
@@ -870,6 +904,8 @@ __global__ __launch_bounds__(WAVE) void k_walk_doc(TRANS tr, DtkWalkArgs A, uint
                                                    uint32_t unknown, uint32_t identity) {
   __shared__ uint16_t s_win[TRANS::LEAN ? WAVE * DTK_WIN_ROW : 8];
   uint16_t *win_row = s_win + (TRANS::LEAN ? threadIdx.x * DTK_WIN_ROW : 0u);
+  __shared__ uint32_t s_el[TRANS::LEAN ? WAVE * DTK_ELIST_ROW : 1];
+  uint32_t *el_row = TRANS::LEAN ? s_el + threadIdx.x * DTK_ELIST_ROW : nullptr;
   const uint32_t d = blockIdx.x * WAVE + threadIdx.x;
   uint32_t steps = 0;
   if (d < A.n_docs) {
@@ -877,7 +913,7 @@ __global__ __launch_bounds__(WAVE) void k_walk_doc(TRANS tr, DtkWalkArgs A, uint
     const uint32_t len = (uint32_t)(A.doc_off[d + 1] - off);
     EventSink sink;
     const uint64_t evb = DTK_EV_BASE(off, d);
-    sink.init(A.evA + evb, A.evB + evb, 0u, 0xFFFFFFFFu);
+    sink.init(A.evA + evb, A.evB + evb, 0u, 0xFFFFFFFFu, el_row);
     DtkLaneState init{0u, tr.start_state(), tr.start_aux(), 0u}, fin;
     uint32_t st;
     walk_any<TRANS, IS_MATRIX, MODE_DOC>(tr, A.sym, off, len, init, 0u, sink, epsilon, unknown,
@@ -1010,6 +1046,8 @@ __global__ __launch_bounds__(WAVE) void k_spec_walk(TRANS tr, DtkWalkArgs A, Dtk
                                                     uint32_t identity) {
   __shared__ uint16_t s_win[TRANS::LEAN ? WAVE * DTK_WIN_ROW : 8];
   uint16_t *win_row = s_win + (TRANS::LEAN ? threadIdx.x * DTK_WIN_ROW : 0u);
+  __shared__ uint32_t s_el[TRANS::LEAN ? WAVE * DTK_ELIST_ROW : 1];
+  uint32_t *el_row = TRANS::LEAN ? s_el + threadIdx.x * DTK_ELIST_ROW : nullptr;
   const uint32_t L = blockIdx.x * WAVE + threadIdx.x;
   uint32_t steps = 0;
   if (L < S.n_lanes) {
@@ -1025,7 +1063,7 @@ __global__ __launch_bounds__(WAVE) void k_spec_walk(TRANS tr, DtkWalkArgs A, Dtk
         const DtkLaneState init = S.lane_start[L];
         EventSink sink;
         const uint64_t evb = DTK_EV_BASE(off, d);
-        sink.init(A.evA + evb, A.evB + evb, init.p, pl.wend);
+        sink.init(A.evA + evb, A.evB + evb, init.p, pl.wend, el_row);
         uint32_t st = 0;
         walk_any<TRANS, IS_MATRIX, MODE_CHUNK>(tr, A.sym, off, len, init, pl.stop, sink, epsilon, unknown,
                                                 identity, step_cap(A.step_factor, len), fin, st, steps, win_row);
