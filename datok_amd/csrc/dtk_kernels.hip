@@ -98,7 +98,6 @@ __global__ __launch_bounds__(WAVE) void k_symbolize(const uint8_t *__restrict__ 
   __shared__ uint16_t s_syms[256];
   __shared__ uint32_t s_txt[SYM_BLOCK_BYTES / 4 + 4];  // the block's bytes, one dword of halo either side
   __shared__ uint16_t s_q[SYM_HALF];  // positions (offset in the block) of the bytes >= 0x80 of one half
-  __shared__ uint32_t s_qn;           // entries queued
   const uint32_t lane = threadIdx.x;
   const bool sig_lds = sig.n_runes <= 256u;
   for (uint32_t i = lane; i < SYM_BLOCK_BYTES / 32; i += WAVE) s_rs[i] = 0;
@@ -146,20 +145,20 @@ __global__ __launch_bounds__(WAVE) void k_symbolize(const uint8_t *__restrict__ 
     if (half * SYM_HALF >= n_here) break;
     // ---- light: every byte < 0x80 is a complete rune: its entry goes straight to memory
     //      (16-byte stores, 8 bytes of input per lane); the positions of the other bytes are queued
-    //      (slots from an LDS counter: the heavy pass does not care about their order)
-    if (lane == 0) s_qn = 0;
-    __syncthreads();
-#pragma unroll 1
-    for (uint32_t it = 0; it < SYM_HALF / SYM_TILE; it++) {
+    //      (slots from a wave-uniform counter and four ballots: an LDS atomicAdd with per-lane
+    //      values compiles to a loop over the active lanes)
+    uint32_t qn = 0;
+    auto light = [&](auto full_tag, uint32_t it) {
+      constexpr bool FULL = decltype(full_tag)::value;  // a whole block, entries 16-byte aligned
       const uint32_t i0 = half * SYM_HALF + it * SYM_TILE + lane * 8u;  // my 8 bytes (offset in the block)
-      if (half * SYM_HALF + it * SYM_TILE >= n_here) break;
       const uint32_t w0 = s_txt[1 + (i0 >> 2)], w1 = s_txt[2 + (i0 >> 2)];
       const uint32_t e0 = lut[w0 & 0x7Fu], e1 = lut[(w0 >> 8) & 0x7Fu];
       const uint32_t e2 = lut[(w0 >> 16) & 0x7Fu], e3 = lut[(w0 >> 24) & 0x7Fu];
       const uint32_t e4 = lut[w1 & 0x7Fu], e5 = lut[(w1 >> 8) & 0x7Fu];
       const uint32_t e6 = lut[(w1 >> 16) & 0x7Fu], e7 = lut[(w1 >> 24) & 0x7Fu];
-      const uint32_t left = i0 < n_here ? (n_here - i0 >= 8u ? 8u : n_here - i0) : 0u;
-      if (left == 8u && sym16) {
+      uint32_t left = 8u;
+      if (!FULL) left = i0 < n_here ? (n_here - i0 >= 8u ? 8u : n_here - i0) : 0u;
+      if (FULL || (left == 8u && sym16)) {
         *reinterpret_cast<uint4 *>(sym + block_start + i0) =
             make_uint4(e0 | (e1 << 16), e2 | (e3 << 16), e4 | (e5 << 16), e6 | (e7 << 16));
       } else {
@@ -167,23 +166,31 @@ __global__ __launch_bounds__(WAVE) void k_symbolize(const uint8_t *__restrict__ 
         for (uint32_t j = 0; j < left; j++) sym[block_start + i0 + j] = (uint16_t)o[j];
       }
       // one bit per byte: bytes < 0x80 start a rune (the others are decided one by one below)
-      const uint32_t lo4 = left >= 4u ? 0xFFFFFFFFu : ((1u << (8u * left)) - 1u);
-      const uint32_t hi4 = left >= 8u ? 0xFFFFFFFFu : (left > 4u ? ((1u << (8u * (left - 4u))) - 1u) : 0u);
-      const uint32_t h0 = (w0 & 0x80808080u) & lo4, h1 = (w1 & 0x80808080u) & hi4;
-      const uint32_t a0 = (~w0 & 0x80808080u) & lo4, a1 = (~w1 & 0x80808080u) & hi4;
       auto nib = [](uint32_t x) { return ((x >> 7) & 1u) | ((x >> 14) & 2u) | ((x >> 21) & 4u) | ((x >> 28) & 8u); };
-      const uint32_t asc = nib(a0) | (nib(a1) << 4);
+      const uint32_t valid = FULL ? 0xFFu : ((1u << left) - 1u);
+      const uint32_t rare = (nib(w0 & 0x80808080u) | (nib(w1 & 0x80808080u) << 4)) & valid;
+      const uint32_t asc = ~rare & valid;
       if (asc) atomicOr(&s_rs[i0 >> 5], asc << (i0 & 31u));
-      const uint32_t rare = nib(h0) | (nib(h1) << 4);
-      if (rare) {
-        uint32_t slot = atomicAdd(&s_qn, (uint32_t)__popc(rare));
+      // queue slots: exclusive prefix of the lanes' counts (0..8) from four ballots
+      const uint32_t cnt = (uint32_t)__popc(rare);
+      const unsigned long long b0 = __ballot(cnt & 1u), b1 = __ballot(cnt & 2u), b2 = __ballot(cnt & 4u),
+                               b3 = __ballot(cnt & 8u);
+      if ((b0 | b1 | b2 | b3) == 0ull) return;  // wave-uniform
+      const unsigned long long lt = lanemask_lt();
+      uint32_t slot = qn + popc(b0 & lt) + 2u * popc(b1 & lt) + 4u * popc(b2 & lt) + 8u * popc(b3 & lt);
+      qn += popc(b0) + 2u * popc(b1) + 4u * popc(b2) + 8u * popc(b3);
 #pragma unroll
-        for (int j = 0; j < 8; j++)
-          if (rare & (1u << j)) s_q[slot++] = (uint16_t)(i0 + j);
-      }
+      for (int j = 0; j < 8; j++)
+        if (rare & (1u << j)) s_q[slot++] = (uint16_t)(i0 + j);
+    };
+    const bool full_block = n_here == SYM_BLOCK_BYTES && sym16;  // wave-uniform
+#pragma unroll 1
+    for (uint32_t it = 0; it < SYM_HALF / SYM_TILE; it++) {
+      if (half * SYM_HALF + it * SYM_TILE >= n_here) break;
+      if (full_block) light(std::true_type{}, it); else light(std::false_type{}, it);
     }
     __syncthreads();
-    const uint32_t nq = s_qn;  // wave-uniform
+    const uint32_t nq = qn;  // wave-uniform
     if (nq == 0) continue;
     // the heavy lanes overwrite single entries written above: those stores must have landed
     // (staging the block's entries in LDS instead costs more in occupancy than this wait: measured)
