@@ -138,6 +138,7 @@ struct DtkSpecArgs {
   const uint8_t *text;              // input bytes (k_spec_start: whitespace-guided warm-up), or null
   uint32_t warm_ws;                 // start the warm-up behind the warm_ws-th whitespace run before the chunk (0: fixed)
   uint32_t warm_min;                // ... looking backwards from chunk start - warm_min
+  uint32_t ev_lists;                // lean walk: collect event bytes in LDS lists (large batches), 0: plain stores
 };
 
 struct DtkWalkArgs {

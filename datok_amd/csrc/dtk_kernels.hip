@@ -1047,14 +1047,14 @@ __global__ __launch_bounds__(256) void k_spec_link(DtkSpecArgs S) {
   if (!linked) atomicMax(&S.first_bad[d], ~(L - L0));  // stored inverted: zero fill = none
 }
 
-template <typename TRANS, bool IS_MATRIX>
+template <typename TRANS, bool IS_MATRIX, bool LISTS>
 __global__ __launch_bounds__(WAVE) void k_spec_walk(TRANS tr, DtkWalkArgs A, DtkSpecArgs S,
                                                     uint32_t epsilon, uint32_t unknown,
                                                     uint32_t identity) {
   __shared__ uint16_t s_win[TRANS::LEAN ? WAVE * DTK_WIN_ROW : 8];
   uint16_t *win_row = s_win + (TRANS::LEAN ? threadIdx.x * DTK_WIN_ROW : 0u);
-  __shared__ uint32_t s_el[TRANS::LEAN ? WAVE * DTK_ELIST_ROW : 1];
-  uint32_t *el_row = TRANS::LEAN ? s_el + threadIdx.x * DTK_ELIST_ROW : nullptr;
+  __shared__ uint32_t s_el[LISTS ? WAVE * DTK_ELIST_ROW : 1];
+  uint32_t *el_row = LISTS ? s_el + threadIdx.x * DTK_ELIST_ROW : nullptr;
   const uint32_t L = blockIdx.x * WAVE + threadIdx.x;
   uint32_t steps = 0;
   if (L < S.n_lanes) {
@@ -1790,7 +1790,14 @@ extern "C" int dtk_launch_spec(const DtkTableDev *tab, const DtkWalkArgs *args, 
     case 2:
       return with_trans(tab, [&](auto tr, auto is_matrix) {
         using TR = decltype(tr);
-        hipLaunchKernelGGL((k_spec_walk<TR, decltype(is_matrix)::value>), dim3(lane_blocks), dim3(WAVE), 0, s,
+        if constexpr (TR::LEAN) {
+          if (spec->ev_lists) {
+            hipLaunchKernelGGL((k_spec_walk<TR, decltype(is_matrix)::value, true>), dim3(lane_blocks), dim3(WAVE), 0,
+                               s, tr, *args, *spec, tab->epsilon, tab->unknown, tab->identity);
+            return;
+          }
+        }
+        hipLaunchKernelGGL((k_spec_walk<TR, decltype(is_matrix)::value, false>), dim3(lane_blocks), dim3(WAVE), 0, s,
                            tr, *args, *spec, tab->epsilon, tab->unknown, tab->identity);
       });
     case 3:
