@@ -1116,11 +1116,18 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
   } else {
     DtkSpecArgs sp = spec_args(b, false);
     uint32_t *n_bad = (uint32_t *)(b->d_totals + 5);
+    // DATOK_SPLIT_START=1: start records and chunk walk as two launches (the repair rounds' kernels)
+    static const bool split = getenv("DATOK_SPLIT_START") && atoi(getenv("DATOK_SPLIT_START")) != 0;
     for (int stage = 0; stage < 5; stage++) {
       if (((skip & 2) && stage <= 1) || ((skip & 4) && stage == 2)) { STAGE(3 + stage); continue; }
-      if (dtk_launch_spec(&m->tab, &w, &sp, stage, cmp_mask_of(m), b->d_redo, n_bad, s))
+      // one launch for start records + walk (timed as "walk"); the link pass, which only reads the
+      // records, then runs in front of the verification
+      const int what = split ? stage : (stage <= 1 ? -1 : stage == 2 ? 6 : stage);
+      if (!split && stage == 3 && dtk_launch_spec(&m->tab, &w, &sp, 1, cmp_mask_of(m), b->d_redo, n_bad, s))
         return hip_fail(hipGetLastError(), "speculative walk");
-      STAGE(3 + stage);  // ends: start records, link, chunk walk, verify, fix
+      if (what >= 0 && dtk_launch_spec(&m->tab, &w, &sp, what, cmp_mask_of(m), b->d_redo, n_bad, s))
+        return hip_fail(hipGetLastError(), "speculative walk");
+      STAGE(3 + stage);  // ends: start records, link, chunk walk, verify, fix (split) / -, -, start + walk, link + verify, fix
     }
   }
   DtkCompactArgs c{};

@@ -947,6 +947,52 @@ __global__ __launch_bounds__(WAVE) void k_walk_doc(TRANS tr, DtkWalkArgs A, uint
 //                  fails is repaired from the first bad lane on (host loop,
 //                  normally never entered) -- the result is exact either way.
 
+// the start record of lane k >= 0 of document d (k_spec_start, k_spec_both)
+template <typename TRANS, bool IS_MATRIX>
+__device__ __forceinline__ DtkLaneState start_record(const TRANS &tr, const DtkWalkArgs &A, const DtkSpecArgs &S,
+                                                     uint32_t k, uint64_t off, uint32_t len, uint32_t epsilon,
+                                                     uint32_t unknown, uint32_t identity, uint16_t *win_row,
+                                                     uint32_t &steps) {
+  const uint16_t *__restrict__ s = A.sym + off;
+  DtkLaneState rec{0u, tr.start_state(), tr.start_aux(), 0u};
+  if (k > 0) {
+    const uint32_t kc = k * S.chunk;
+    uint32_t sp = kc > S.warm ? kc - S.warm : 0u;
+    if (sp > 0 && S.warm_ws && S.text) {
+      // The walk re-synchronises at token boundaries, and blanks are boundaries in every
+      // tokenizer of this kind: start behind the warm_ws-th run of blanks before the chunk
+      // instead of a fixed distance (never further back than `warm`).  A wrong guess only
+      // costs a repair round.
+      const uint8_t *tx = S.text + off;
+      uint32_t runs = 0, q = kc > S.warm_min ? kc - S.warm_min : 0u;
+      if (q < sp) q = sp;
+      bool in_ws = false;
+      while (q > sp) {
+        const uint8_t c = tx[q - 1u];
+        const bool ws = c == ' ' || c == '\n' || c == '\t' || c == '\r';
+        if (in_ws && !ws) { if (++runs == S.warm_ws) break; }
+        in_ws = ws;
+        q--;
+      }
+      sp = q;  // first byte of the run of blanks (the walk skips them), or the fixed start
+    }
+    EventSink sink;
+    sink.init(nullptr, nullptr, 0u, 0u);
+    uint32_t st;
+    if (sp > 0) {
+      while (sp < len && !(s[sp] & DTK_SYM_START)) sp++;
+      DtkLaneState init{sp, tr.start_state(), tr.start_aux(), 0u};
+      walk_any<TRANS, IS_MATRIX, MODE_START>(tr, A.sym, off, len, init, kc, sink, epsilon, unknown,
+                                              identity, step_cap(A.step_factor, len), rec, st, steps, win_row);
+    } else {
+      // sp == 0: the walk from the true initial state; its first sync point at/after kc
+      walk_any<TRANS, IS_MATRIX, MODE_START>(tr, A.sym, off, len, rec, kc, sink, epsilon, unknown,
+                                              identity, step_cap(A.step_factor, len), rec, st, steps, win_row);
+    }
+  }
+  return rec;
+}
+
 template <typename TRANS, bool IS_MATRIX>
 __global__ __launch_bounds__(WAVE) void k_spec_start(TRANS tr, DtkWalkArgs A, DtkSpecArgs S,
                                                      uint32_t epsilon, uint32_t unknown,
@@ -958,52 +1004,52 @@ __global__ __launch_bounds__(WAVE) void k_spec_start(TRANS tr, DtkWalkArgs A, Dt
   if (L < S.n_lanes) {
     const uint32_t d = S.lane_doc[L];
     const uint32_t k = L - S.chunk_off[d];
-    {
-      const uint64_t off = A.doc_off[d];
-      const uint32_t len = (uint32_t)(A.doc_off[d + 1] - off);
-      const uint16_t *__restrict__ s = A.sym + off;
-      DtkLaneState rec{0u, tr.start_state(), tr.start_aux(), 0u};
-      if (k > 0) {
-        const uint32_t kc = k * S.chunk;
-        uint32_t sp = kc > S.warm ? kc - S.warm : 0u;
-        if (sp > 0 && S.warm_ws && S.text) {
-          // The walk re-synchronises at token boundaries, and blanks are boundaries in every
-          // tokenizer of this kind: start behind the warm_ws-th run of blanks before the chunk
-          // instead of a fixed distance (never further back than `warm`).  A wrong guess only
-          // costs a repair round.
-          const uint8_t *tx = S.text + off;
-          uint32_t runs = 0, q = kc > S.warm_min ? kc - S.warm_min : 0u;
-          if (q < sp) q = sp;
-          bool in_ws = false;
-          while (q > sp) {
-            const uint8_t c = tx[q - 1u];
-            const bool ws = c == ' ' || c == '\n' || c == '\t' || c == '\r';
-            if (in_ws && !ws) { if (++runs == S.warm_ws) break; }
-            in_ws = ws;
-            q--;
-          }
-          sp = q;  // first byte of the run of blanks (the walk skips them), or the fixed start
-        }
-        if (sp > 0) {
-          while (sp < len && !(s[sp] & DTK_SYM_START)) sp++;
-          DtkLaneState init{sp, tr.start_state(), tr.start_aux(), 0u};
-          EventSink sink;
-          sink.init(nullptr, nullptr, 0u, 0u);
-          uint32_t st;
-          walk_any<TRANS, IS_MATRIX, MODE_START>(tr, A.sym, off, len, init, kc, sink, epsilon, unknown,
-                                                  identity, step_cap(A.step_factor, len), rec, st, steps, win_row);
-        }
-        // sp == 0: the walk from the true initial state; its first sync point at/after kc
-        else {
-          EventSink sink;
-          sink.init(nullptr, nullptr, 0u, 0u);
-          uint32_t st;
-          walk_any<TRANS, IS_MATRIX, MODE_START>(tr, A.sym, off, len, rec, kc, sink, epsilon, unknown,
-                                                  identity, step_cap(A.step_factor, len), rec, st, steps, win_row);
-        }
-      }
-      S.lane_start[L] = rec;
+    const uint64_t off = A.doc_off[d];
+    const uint32_t len = (uint32_t)(A.doc_off[d + 1] - off);
+    S.lane_start[L] = start_record<TRANS, IS_MATRIX>(tr, A, S, k, off, len, epsilon, unknown, identity, win_row, steps);
+  }
+  add_steps(A.steps, steps);
+}
+
+// First pass in one launch: the lane finds its start record (as k_spec_start) and walks on from it
+// to its first sync point at or behind the end of its chunk -- which is the record its successor
+// finds for itself if the speculation holds, and k_spec_verify checks exactly that.  Every lane
+// with a record walks; what lanes behind a broken chain stored is cleared by the repair round.
+template <typename TRANS, bool IS_MATRIX, bool LISTS>
+__global__ __launch_bounds__(WAVE) void k_spec_both(TRANS tr, DtkWalkArgs A, DtkSpecArgs S,
+                                                    uint32_t epsilon, uint32_t unknown,
+                                                    uint32_t identity) {
+  __shared__ uint16_t s_win[TRANS::LEAN ? WAVE * DTK_WIN_ROW : 8];
+  uint16_t *win_row = s_win + (TRANS::LEAN ? threadIdx.x * DTK_WIN_ROW : 0u);
+  __shared__ uint32_t s_el[LISTS ? WAVE * DTK_ELIST_ROW : 1];
+  uint32_t *el_row = LISTS ? s_el + threadIdx.x * DTK_ELIST_ROW : nullptr;
+  const uint32_t L = blockIdx.x * WAVE + threadIdx.x;
+  uint32_t steps = 0;
+  if (L < S.n_lanes) {
+    const uint32_t d = S.lane_doc[L];
+    const uint32_t k = L - S.chunk_off[d];
+    const uint64_t off = A.doc_off[d];
+    const uint32_t len = (uint32_t)(A.doc_off[d + 1] - off);
+    const DtkLaneState rec =
+        start_record<TRANS, IS_MATRIX>(tr, A, S, k, off, len, epsilon, unknown, identity, win_row, steps);
+    S.lane_start[L] = rec;
+    DtkLaneState fin{0xFFFFFFFFu, 0u, 0u, LANE_F_IDLE};
+    DtkLaneCount cnt{0u, 0u, 0u, 0u, 0u, 0xFFFFFFFFu, 0u, 0u};
+    if (rec.p != 0xFFFFFFFFu) {
+      const uint32_t stop = (L + 1u < S.chunk_off[d + 1]) ? (k + 1u) * S.chunk : 0xFFFFFFFFu;
+      EventSink sink;
+      const uint64_t evb = DTK_EV_BASE(off, d);
+      sink.init(A.evA + evb, A.evB + evb, rec.p, 0xFFFFFFFFu, el_row);
+      uint32_t st = 0, steps2 = 0;
+      walk_any<TRANS, IS_MATRIX, MODE_CHUNK>(tr, A.sym, off, len, rec, stop, sink, epsilon, unknown,
+                                              identity, step_cap(A.step_factor, len), fin, st, steps2, win_row);
+      steps += steps2;
+      if (sink.dropped) fin.flags |= LANE_F_DROPPED;
+      cnt.tok = sink.c_tok; cnt.sent = sink.c_sent; cnt.text = sink.c_text; cnt.status = st | sink.st;
+      cnt.sev = sink.c_sev; cnt.e_pos = sink.e_pos; cnt.e_tok = sink.e_tok;
     }
+    S.lane_end[L] = fin;
+    S.lane_cnt[L] = cnt;
   }
   add_steps(A.steps, steps);
 }
@@ -1767,7 +1813,7 @@ extern "C" int dtk_launch_walk(const DtkTableDev *tab, const DtkWalkArgs *args, 
   });
 }
 
-// stage: 0 start records, 1 link, 2 walk, 3 verify, 4 fix (first pass);
+// stage: 6 start records + walk, 1 link, 3 verify, 4 fix (first pass; or 0 start records, 1, 2 walk, 3, 4);
 //        5 clear, 6 plan, 2 walk, 7 check (repair rounds, spec->redo_from set)
 extern "C" int dtk_launch_spec(const DtkTableDev *tab, const DtkWalkArgs *args, const DtkSpecArgs *spec,
                                int stage, uint32_t cmp_mask, uint32_t *redo_out, uint32_t *n_bad,
@@ -1782,6 +1828,19 @@ extern "C" int dtk_launch_spec(const DtkTableDev *tab, const DtkWalkArgs *args, 
       return with_trans(tab, [&](auto tr, auto is_matrix) {
         using TR = decltype(tr);
         hipLaunchKernelGGL((k_spec_start<TR, decltype(is_matrix)::value>), dim3(lane_blocks), dim3(WAVE), 0, s,
+                           tr, *args, *spec, tab->epsilon, tab->unknown, tab->identity);
+      });
+    case 6:  // first pass: start records and chunk walk in one launch
+      return with_trans(tab, [&](auto tr, auto is_matrix) {
+        using TR = decltype(tr);
+        if constexpr (TR::LEAN) {
+          if (spec->ev_lists) {
+            hipLaunchKernelGGL((k_spec_both<TR, decltype(is_matrix)::value, true>), dim3(lane_blocks), dim3(WAVE), 0,
+                               s, tr, *args, *spec, tab->epsilon, tab->unknown, tab->identity);
+            return;
+          }
+        }
+        hipLaunchKernelGGL((k_spec_both<TR, decltype(is_matrix)::value, false>), dim3(lane_blocks), dim3(WAVE), 0, s,
                            tr, *args, *spec, tab->epsilon, tab->unknown, tab->identity);
       });
     case 1:

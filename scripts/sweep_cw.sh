@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for cw in "128 48" "128 40" "160 48" "192 48" "192 40" "256 48" "128 48"; do
+for cw in "128 48" "96 48" "160 48" "192 48" "256 48" "128 40" "128 32" "128 48"; do
   set -- $cw
   python bench.py --chunk $1 --warm $2 --streams ${STREAMS:-3} --steps 60 --warmup 6 --no-cpu-baseline --parity-docs 32 2>/dev/null | python -c "
 import sys,json
