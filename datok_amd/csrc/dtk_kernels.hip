@@ -767,7 +767,10 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
     // the rune at p (an epsilon iteration reads none: the entry is then not used)
     const uint32_t e = e_next;
     const uint32_t a = r ? epsilon : (e & DTK_SYM_MASK);
-    const uint32_t x = tab[(size_t)t * stride + a];
+    // the fused table is at most 2^15 states x 2^11 symbols x 4 B: a 32-bit byte offset from the
+    // uniform base (one 24-bit multiply-add) instead of 64-bit address arithmetic
+    const uint32_t x = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(tab) +
+                                                           ((__umul24(t, stride) + a) << 2));
     // while the cell is on its way: the entry of the position the next rune is read from (behind
     // this rune; after a backtrack the epsilon iteration, which reads no rune, does this for the
     // position it returns to)
