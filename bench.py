@@ -51,6 +51,19 @@ def parse():
     return ap.parse_args()
 
 
+def walk_kernel_name(total_bytes):
+    """The dominant kernel as rocprofv3 prints it: start record + chunk walk in one launch (k_spec_both) unless
+    DATOK_SPLIT_START=1; its last template argument says whether event bytes go through LDS lists
+    (batches of 48 MiB and more, dtk_host.cpp spec_args)."""
+    if os.environ.get("DATOK_SPLIT_START", "0") not in ("", "0"):
+        base = "k_spec_walk"
+    else:
+        base = "k_spec_both"
+    e = os.environ.get("DATOK_EV_LISTS")
+    lists = (e not in ("", "0")) if e is not None else total_bytes >= int(os.environ.get("DATOK_EV_LISTS_MIN", 48 << 20))
+    return base + "<%s, true, " + ("true" if lists else "false") + ">"
+
+
 def main():
     args = parse()
     import torch
@@ -231,7 +244,8 @@ def main():
         b_alg = total + 4 * (args.docs + 1) + 4 * (2 * tot["n_tokens"] + tot["n_sent"]) + 8 * args.docs
         walk_s = stage_avg["walk"] * 1e-3
         achieved = b_alg / walk_s / 1e9
-        both_s = (stage_avg["walk"] + stage_avg["spec_start"]) * 1e-3
+        split = os.environ.get("DATOK_SPLIT_START", "0") not in ("", "0")
+        both_s = (stage_avg["walk"] + (stage_avg["spec_start"] if split else 0.0)) * 1e-3
         # HBM bytes of that kernel from the last committed rocprofv3 --pmc passes (profiles/)
         traffic = None
         try:
@@ -252,7 +266,7 @@ def main():
                        "parallelism": "documents sharded over %d GPU(s), no data-path collective" % world,
                        "batches_in_flight": len(batches)},
             "roofline": {"bound": "hbm",
-                         "kernel": ("k_spec_walk<%s, true>" if tot["chunk_bytes"] else "k_walk_doc<%s, true>") % (
+                         "kernel": (walk_kernel_name(total) if tot["chunk_bytes"] else "k_walk_doc<%s, true>") % (
                              ("MatrixLeanTrans" if not tok.info["unknown_used"] else "MatrixFusedTrans")
                              if tok.info["entry_bytes"] == 4 and tok.info["state_count"] < 32767
                              else "MatrixTrans<u%d>" % (8 * tok.info["entry_bytes"])),

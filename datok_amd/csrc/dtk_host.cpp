@@ -1087,7 +1087,7 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
   STAGE(0);
   {
     // carve the accumulator block for this run's document count: totals, counts, status,
-    // check words -- all cleared by one memset; the two event arrays by a second one
+    // check words -- cleared together with the two event arrays by one launch
     const size_t nd = b->n_docs;
     uint8_t *q = b->d_acc;
     b->d_totals = (uint64_t *)q; q += 64;
@@ -1097,11 +1097,12 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
     b->d_status = (uint32_t *)q; q += nd * 4;
     b->d_first_bad = (uint32_t *)q; q += nd * 4;
     b->d_fail_lane = (uint32_t *)q; q += nd * 4;
-    HIP_TRY(hipMemsetAsync(b->d_acc, 0, (size_t)(q - b->d_acc), s));
+    const size_t acc_used = ((size_t)(q - b->d_acc) + 15) & ~(size_t)15;  // the block has 64 bytes of slack
     const size_t ev_bytes = (b->total + 4 * nd + 4 + 255) & ~(size_t)255;
     b->d_evA = b->d_ev;
     b->d_evB = b->d_ev + ev_bytes;
-    if (!(skip & 4)) HIP_TRY(hipMemsetAsync(b->d_ev, 0, 2 * ev_bytes, s));
+    if (dtk_launch_clear2(b->d_acc, acc_used, b->d_ev, (skip & 4) ? 0 : 2 * ev_bytes, s))
+      return hip_fail(hipGetLastError(), "clear");
   }
   STAGE(1);
   if (!(skip & 1) && dtk_launch_symbolize(b->d_text, b->d_off, b->n_docs, b->total, &m->sig, b->d_sym,

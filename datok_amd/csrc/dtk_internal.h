@@ -241,6 +241,7 @@ int dtk_launch_compact(const struct DtkCompactArgs *args, int pass, void *stream
 int dtk_launch_seg_prepare(const struct DtkCompactArgs *args, const uint32_t *doc_seg0, void *stream);
 int dtk_launch_render(const struct DtkRenderArgs *args, int stage, void *stream);
 uint32_t dtk_render_tiles(uint64_t n);
+int dtk_launch_clear2(void *a, uint64_t a_bytes, void *b, uint64_t b_bytes, void *stream);
 int dtk_launch_scan3(const uint64_t *ca, const uint64_t *cb, const uint64_t *cc, uint64_t *a, uint64_t *b,
                      uint64_t *c, uint32_t n_docs, uint64_t *totals, const uint32_t *status, uint64_t *ws,
                      void *stream);

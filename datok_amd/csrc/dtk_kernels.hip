@@ -1762,6 +1762,27 @@ __global__ __launch_bounds__(1024) void k_scan3(const uint64_t *ca, const uint64
 
 // ---------------------------------------------------------------- launchers
 
+// ---- clears: the accumulator block and the two event arrays of a run in one launch (16-byte stores)
+__global__ __launch_bounds__(256) void k_clear2(uint4 *__restrict__ a, uint64_t na16, uint4 *__restrict__ b,
+                                                uint64_t nb16) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < na16 + nb16; i += stride) {
+    if (i < na16) a[i] = z; else b[i - na16] = z;
+  }
+}
+
+// both pointers 16-byte aligned, both sizes multiples of 16
+extern "C" int dtk_launch_clear2(void *a, uint64_t a_bytes, void *b, uint64_t b_bytes, void *stream) {
+  const uint64_t n16 = (a_bytes + b_bytes) / 16;
+  if (n16 == 0) return 0;
+  uint64_t blocks = (n16 + 256ull * 4 - 1) / (256ull * 4);  // 4 stores per thread
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_clear2, dim3((uint32_t)blocks), dim3(256), 0, (hipStream_t)stream, (uint4 *)a, a_bytes / 16,
+                     (uint4 *)b, b_bytes / 16);
+  return (int)hipGetLastError();
+}
+
 extern "C" int dtk_launch_symbolize(const uint8_t *text, const uint64_t *doc_off, uint32_t n_docs,
                                     uint64_t total, const DtkSigmaDev *sig, uint16_t *sym, int padded,
                                     const uint32_t *blk_doc, unsigned long long *n_invalid, uint32_t *rs_bits,
