@@ -508,23 +508,37 @@ __device__ __noinline__ uint32_t count_runes(const uint16_t *__restrict__ s, uin
   return n;
 }
 
+// window of the symbol stream in LDS (see walk_fused)
+typedef uint2 __attribute__((may_alias)) dtk_u2a;
+typedef uint16_t __attribute__((may_alias)) dtk_u16a;
+__device__ __forceinline__ void win_fill(dtk_u16a *row, const uint16_t *__restrict__ aligned, uint32_t wbase) {
+  const uint4 *__restrict__ g = reinterpret_cast<const uint4 *>(aligned + wbase);
+  const uint4 v0 = g[0], v1 = g[1], v2 = g[2], v3 = g[3];
+  dtk_u2a *r = reinterpret_cast<dtk_u2a *>(row);
+  r[0] = make_uint2(v0.x, v0.y); r[1] = make_uint2(v0.z, v0.w);
+  r[2] = make_uint2(v1.x, v1.y); r[3] = make_uint2(v1.z, v1.w);
+  r[4] = make_uint2(v2.x, v2.y); r[5] = make_uint2(v2.z, v2.w);
+  r[6] = make_uint2(v3.x, v3.y); r[7] = make_uint2(v3.z, v3.w);
+}
+
 // The walk of matrix.go:348-698 / datok.go:781-1135 for one lane.
 // Returns through `fin`: p == 0xFFFFFFFF means "ran to EOF" (MODE_START: no
 // rewind found; otherwise: tail done).
 //
 // The reference's rune window is not materialised: p / tp / bs / hi are byte
 // positions of buffer[buffc] / buffer[bufft] / buffer[0] / buffer[buffi], and the
-// symbol stream (4 entries per 8-byte load, the next group always in flight)
-// replaces the rune -> symbol lookups of matrix.go:421-435.
+// symbol stream (read through the lane's window in LDS) replaces the rune -> symbol lookups
+// of matrix.go:421-435.
 template <typename TRANS, bool IS_MATRIX, int MODE>
 __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__restrict__ sym_base,
                                           uint64_t off, uint32_t len, DtkLaneState init, uint32_t stop_pos,
                                           EventSink &sink, uint32_t epsilon, uint32_t unknown,
                                           uint32_t identity, uint32_t cap, DtkLaneState &fin,
-                                          uint32_t &st_out, uint32_t &steps_out) {
-  // symbol stream addressed in aligned groups of 4 entries
-  const uint32_t o3 = (uint32_t)(off & 3u);
-  const uint64_t *__restrict__ sq = reinterpret_cast<const uint64_t *>(sym_base + (off - o3));
+                                          uint32_t &st_out, uint32_t &steps_out, uint16_t *win_row) {
+  // the lane's window of the symbol stream in LDS: entries (pos + o7) in [wbase, wbase + DTK_WIN)
+  dtk_u16a *row = reinterpret_cast<dtk_u16a *>(win_row);
+  const uint32_t o7 = (uint32_t)(off & 7u);
+  const uint16_t *__restrict__ aligned = sym_base + (off - o7);
   const uint16_t *__restrict__ s = sym_base + off;
 
   uint32_t a = 0, t0 = 0, aux0 = 0;
@@ -548,8 +562,8 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
   bool any_tok = init.p > 0;               // some Token call happened (else sentB is still true)
   bool has_tok = init.p > 0 && !text_end;  // pos[] of the current text is not empty
 
-  uint32_t grp = 0xFFFFFFFEu;    // group index held in q_cur; q_next holds grp + 1 (none yet)
-  uint64_t q_cur = 0, q_next = 0;
+  uint32_t wbase = (init.p + o7) & ~7u;
+  win_fill(row, aligned, wbase);
 
   // One table lookup per iteration (the reference's loop body, matrix.go:384-635),
   // written as predicates + selects so that the 64 lanes of a wave, which are all
@@ -569,15 +583,13 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
       newchar = false;
       done = !he && !bt;
     }
+    // a lane that needs a rune outside its window: all lanes of the wave re-base theirs
+    if (__builtin_amdgcn_ballot_w64(newchar && (p + o7 - wbase) >= DTK_WIN) != 0ull) {
+      wbase = (p + o7) & ~7u;
+      win_fill(row, aligned, wbase);
+    }
     if (newchar) {
-      const uint32_t i = p + o3, g = i >> 2;
-      if (g != grp) {
-        q_cur = (g == grp + 1u) ? q_next : sq[g];  // else: after a backtrack / at the start
-        q_next = sq[g + 1u];                       // in flight for the next ~4 runes
-        grp = g;
-      }
-      const uint32_t half = (i & 2u) ? (uint32_t)(q_cur >> 32) : (uint32_t)q_cur;
-      const uint32_t e = (i & 1u) ? (half >> 16) : (half & 0xFFFFu);
+      const uint32_t e = row[p + o7 - wbase];
       a = e & DTK_SYM_MASK;
       w = ((e >> DTK_SYM_W_SHIFT) & 3u) + 1u;
       const uint32_t cls = (e >> DTK_SYM_CLS_SHIFT) & 3u;
@@ -709,18 +721,6 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
 // when any lane of the wave leaves its window all lanes re-base theirs (a wave-uniform branch,
 // once per ~28 iterations).  Read straight from memory in 8-byte groups, the lanes' 64 stream
 // lines and the table lines evict each other from the 32 KiB L1 and every group load goes to L2.
-typedef uint2 __attribute__((may_alias)) dtk_u2a;
-typedef uint16_t __attribute__((may_alias)) dtk_u16a;
-__device__ __forceinline__ void win_fill(dtk_u16a *row, const uint16_t *__restrict__ aligned, uint32_t wbase) {
-  const uint4 *__restrict__ g = reinterpret_cast<const uint4 *>(aligned + wbase);
-  const uint4 v0 = g[0], v1 = g[1], v2 = g[2], v3 = g[3];
-  dtk_u2a *r = reinterpret_cast<dtk_u2a *>(row);
-  r[0] = make_uint2(v0.x, v0.y); r[1] = make_uint2(v0.z, v0.w);
-  r[2] = make_uint2(v1.x, v1.y); r[3] = make_uint2(v1.z, v1.w);
-  r[4] = make_uint2(v2.x, v2.y); r[5] = make_uint2(v2.z, v2.w);
-  r[6] = make_uint2(v3.x, v3.y); r[7] = make_uint2(v3.z, v3.w);
-}
-
 template <int MODE>
 __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uint16_t *__restrict__ sym_base,
                                            uint64_t off, uint32_t len, DtkLaneState init, uint32_t stop_pos,
@@ -893,7 +893,7 @@ __device__ __forceinline__ void walk_any(const TRANS &tr, const uint16_t *__rest
     walk_fused<MODE>(tr, sym_base, off, len, init, stop_pos, sink, epsilon, cap, fin, st_out, steps_out, win_row);
   else
     walk_lane<TRANS, IS_MATRIX, MODE>(tr, sym_base, off, len, init, stop_pos, sink, epsilon, unknown, identity, cap,
-                                      fin, st_out, steps_out);
+                                      fin, st_out, steps_out, win_row);
 }
 
 __device__ __forceinline__ uint32_t step_cap(uint32_t factor, uint32_t len) {
@@ -912,8 +912,8 @@ __device__ __forceinline__ void add_steps(unsigned long long *counter, uint32_t 
 template <typename TRANS, bool IS_MATRIX>
 __global__ __launch_bounds__(WAVE) void k_walk_doc(TRANS tr, DtkWalkArgs A, uint32_t epsilon,
                                                    uint32_t unknown, uint32_t identity) {
-  __shared__ uint16_t s_win[TRANS::LEAN ? WAVE * DTK_WIN_ROW : 8];
-  uint16_t *win_row = s_win + (TRANS::LEAN ? threadIdx.x * DTK_WIN_ROW : 0u);
+  __shared__ uint16_t s_win[WAVE * DTK_WIN_ROW];
+  uint16_t *win_row = s_win + threadIdx.x * DTK_WIN_ROW;
   __shared__ uint32_t s_el[TRANS::LEAN ? WAVE * DTK_ELIST_ROW : 1];
   uint32_t *el_row = TRANS::LEAN ? s_el + threadIdx.x * DTK_ELIST_ROW : nullptr;
   const uint32_t d = blockIdx.x * WAVE + threadIdx.x;
@@ -1000,8 +1000,8 @@ template <typename TRANS, bool IS_MATRIX>
 __global__ __launch_bounds__(WAVE) void k_spec_start(TRANS tr, DtkWalkArgs A, DtkSpecArgs S,
                                                      uint32_t epsilon, uint32_t unknown,
                                                      uint32_t identity) {
-  __shared__ uint16_t s_win[TRANS::LEAN ? WAVE * DTK_WIN_ROW : 8];
-  uint16_t *win_row = s_win + (TRANS::LEAN ? threadIdx.x * DTK_WIN_ROW : 0u);
+  __shared__ uint16_t s_win[WAVE * DTK_WIN_ROW];
+  uint16_t *win_row = s_win + threadIdx.x * DTK_WIN_ROW;
   const uint32_t L = blockIdx.x * WAVE + threadIdx.x;
   uint32_t steps = 0;
   if (L < S.n_lanes) {
@@ -1022,8 +1022,8 @@ template <typename TRANS, bool IS_MATRIX, bool LISTS>
 __global__ __launch_bounds__(WAVE) void k_spec_both(TRANS tr, DtkWalkArgs A, DtkSpecArgs S,
                                                     uint32_t epsilon, uint32_t unknown,
                                                     uint32_t identity) {
-  __shared__ uint16_t s_win[TRANS::LEAN ? WAVE * DTK_WIN_ROW : 8];
-  uint16_t *win_row = s_win + (TRANS::LEAN ? threadIdx.x * DTK_WIN_ROW : 0u);
+  __shared__ uint16_t s_win[WAVE * DTK_WIN_ROW];
+  uint16_t *win_row = s_win + threadIdx.x * DTK_WIN_ROW;
   __shared__ uint32_t s_el[LISTS ? WAVE * DTK_ELIST_ROW : 1];
   uint32_t *el_row = LISTS ? s_el + threadIdx.x * DTK_ELIST_ROW : nullptr;
   const uint32_t L = blockIdx.x * WAVE + threadIdx.x;
@@ -1100,8 +1100,8 @@ template <typename TRANS, bool IS_MATRIX, bool LISTS>
 __global__ __launch_bounds__(WAVE) void k_spec_walk(TRANS tr, DtkWalkArgs A, DtkSpecArgs S,
                                                     uint32_t epsilon, uint32_t unknown,
                                                     uint32_t identity) {
-  __shared__ uint16_t s_win[TRANS::LEAN ? WAVE * DTK_WIN_ROW : 8];
-  uint16_t *win_row = s_win + (TRANS::LEAN ? threadIdx.x * DTK_WIN_ROW : 0u);
+  __shared__ uint16_t s_win[WAVE * DTK_WIN_ROW];
+  uint16_t *win_row = s_win + threadIdx.x * DTK_WIN_ROW;
   __shared__ uint32_t s_el[LISTS ? WAVE * DTK_ELIST_ROW : 1];
   uint32_t *el_row = LISTS ? s_el + threadIdx.x * DTK_ELIST_ROW : nullptr;
   const uint32_t L = blockIdx.x * WAVE + threadIdx.x;
