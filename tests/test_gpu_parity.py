@@ -2,6 +2,7 @@
 against the reference's golden vectors.  Bit exact: all outputs are integers."""
 import io
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -526,3 +527,46 @@ def test_double_array_long_documents(gpu, oracle_models):
     a, _ = run_batch(gpu("tokenizer_de.matok"), text, off, NEWLINE_AFTER_EOT, chunk=128)
     for d in (0, 4, 5):   # without EOT both encodings give the same offsets
         assert np.array_equal(a.doc(d)["tok_rstart"], res.doc(d)["tok_rstart"])
+
+
+_VARIANT_SCRIPT = r"""
+import os, sys
+import numpy as np
+ROOT = sys.argv[1]
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import datok_amd
+from datok_amd import corpus
+from oracle import oracle as O
+from parity import assert_batch_equals_oracle
+M = os.path.join(ROOT, "tests", "golden", "models")
+for name, (text, off) in (("tokenizer_de.matok", corpus.german_docs(96, 4096, seed=11)),
+                          ("tokenizer_en.matok", corpus.english_zipf_docs(64, seed=12, max_bytes=8192)),
+                          ("tokenizer_de.datok", corpus.german_docs(32, 2048, seed=13))):
+    tok = datok_amd.load_tokenizer_file(os.path.join(M, name)); om = O.Model(os.path.join(M, name))
+    for chunk, warm in ((None, 48), (64, 8), (256, 48)):
+        with datok_amd.Batch(len(text), len(off) - 1) as b:
+            if chunk is not None:
+                b.set_chunking(chunk, warm)
+            b.set_input(text, off); b.run(tok, 0)
+            res = b.result()
+            keep = [d for d in range(len(off) - 1) if not (res.status[d] & datok_amd.ST_IRREGULAR)]
+            assert len(keep) > (len(off) - 1) // 2
+            assert_batch_equals_oracle(om, res, text, off, docs=keep)
+print("VARIANT OK")
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"DATOK_EV_LISTS": "1"}, {"DATOK_EV_LISTS": "0"}, {"DATOK_SPLIT_START": "1"},
+                                 {"DATOK_SPLIT_START": "1", "DATOK_EV_LISTS": "1"}],
+                         ids=["event-lists", "plain-stores", "split-start", "split-start+lists"])
+def test_kernel_variants_forced_by_environment(env, tmp_path):
+    """The library picks the walk's kernels by batch size (event lists from 48 MiB on) and runs the first pass
+    as one launch; the other paths (small batches through lists, start records and walk as two launches, which is
+    also what repair rounds use) must give the same offsets.  The switches are read once per process."""
+    import subprocess
+    script = tmp_path / "variant.py"
+    script.write_text(_VARIANT_SCRIPT)
+    e = dict(os.environ); e.update(env)
+    r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, env=e, timeout=600)
+    assert r.returncode == 0 and b"VARIANT OK" in r.stdout, r.stderr.decode()[-2000:]
