@@ -81,7 +81,7 @@ __device__ __forceinline__ uint32_t doc_of(const uint64_t *__restrict__ doc_off,
 
 #define SYM_BLOCK_BYTES DTK_SYM_BLOCK_BYTES
 #define SYM_TILE 512u
-#define SYM_HALF 2048u  // the heavy pass runs once per this many bytes
+#define SYM_HALF 1024u  // the heavy pass runs once per this many bytes (its queue: 2 B of LDS per byte)
 
 template <bool ALIGNED4>
 __global__ __launch_bounds__(WAVE) void k_symbolize(const uint8_t *__restrict__ text,
@@ -513,12 +513,15 @@ typedef uint2 __attribute__((may_alias)) dtk_u2a;
 typedef uint16_t __attribute__((may_alias)) dtk_u16a;
 __device__ __forceinline__ void win_fill(dtk_u16a *row, const uint16_t *__restrict__ aligned, uint32_t wbase) {
   const uint4 *__restrict__ g = reinterpret_cast<const uint4 *>(aligned + wbase);
-  const uint4 v0 = g[0], v1 = g[1], v2 = g[2], v3 = g[3];
+  uint4 v[DTK_WIN / 8u];
+#pragma unroll
+  for (uint32_t i = 0; i < DTK_WIN / 8u; i++) v[i] = g[i];  // all loads before the first LDS write
   dtk_u2a *r = reinterpret_cast<dtk_u2a *>(row);
-  r[0] = make_uint2(v0.x, v0.y); r[1] = make_uint2(v0.z, v0.w);
-  r[2] = make_uint2(v1.x, v1.y); r[3] = make_uint2(v1.z, v1.w);
-  r[4] = make_uint2(v2.x, v2.y); r[5] = make_uint2(v2.z, v2.w);
-  r[6] = make_uint2(v3.x, v3.y); r[7] = make_uint2(v3.z, v3.w);
+#pragma unroll
+  for (uint32_t i = 0; i < DTK_WIN / 8u; i++) {
+    r[2 * i] = make_uint2(v[i].x, v[i].y);
+    r[2 * i + 1] = make_uint2(v[i].z, v[i].w);
+  }
 }
 
 // The walk of matrix.go:348-698 / datok.go:781-1135 for one lane.
