@@ -29,15 +29,18 @@ __device__ __forceinline__ unsigned long long lanemask_lt() { return (1ull << la
 __device__ __forceinline__ int highest(unsigned long long m) { return 63 - __clzll((long long)m); }
 __device__ __forceinline__ uint32_t popc(unsigned long long m) { return (uint32_t)__popcll(m); }
 
-// exclusive prefix sum over the 64 lanes; total = sum of all lanes
+// exclusive prefix sum over the 64 lanes; total = sum of all lanes.  DPP row shifts inside the
+// rows of 16 lanes, then the two row broadcasts (lane 15 -> next row, lane 31 -> upper half):
+// six adds, no LDS traffic (a __shfl_up ladder is six ds_bpermute round trips).
 __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total) {
   uint32_t x = v;
-#pragma unroll
-  for (int o = 1; o < WAVE; o <<= 1) {
-    uint32_t y = __shfl_up(x, o);
-    if ((int)lane_id() >= o) x += y;
-  }
-  total = __shfl(x, WAVE - 1);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);  // row_shr:1
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);  // row_shr:2
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);  // row_shr:4
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);  // row_shr:8
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false); // row_bcast:15 -> rows 1, 3
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false); // row_bcast:31 -> rows 2, 3
+  total = (uint32_t)__builtin_amdgcn_readlane((int)x, WAVE - 1);
   return x - v;
 }
 
@@ -1473,7 +1476,7 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
     const uint32_t seAtPrev_t = __shfl(eBeforeEnd + sBeforeEnd, jp);
     const uint32_t eAtPrev_t = __shfl(eBeforeEnd, jp);
     const uint32_t RatPrev_t = __shfl(R, jp);
-    const uint32_t byteAtPrev_t = __shfl(tb, jp);
+    const uint32_t byteAtPrev_t = nl_rule ? __shfl(tb, jp) : 0u;
     const uint32_t seAtPrev = havePrev ? seAtPrev_t : cSEatEnd;
     const uint32_t eAtPrev = havePrev ? eAtPrev_t : cEatEnd;
     const uint32_t RatPrev = havePrev ? RatPrev_t : cLastEndR;
@@ -1487,9 +1490,12 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
     const unsigned long long mPrevE = mEEOT & lt;
     const bool haveE = mPrevE != 0ull;
     const int je = haveE ? highest(mPrevE) : 0;
-    const uint32_t RatE_t = __shfl(R, je);
-    const uint32_t byteAtE_t = __shfl(tb, je);
-    const uint32_t tokAtE_t = __shfl(te, je);  // an E_EOT precedes a token end at its own position
+    uint32_t RatE_t = 0, byteAtE_t = 0, tokAtE_t = 0;
+    if (mEEOT) {  // wave-uniform: most rounds hold no EOT
+      RatE_t = __shfl(R, je);
+      byteAtE_t = __shfl(tb, je);
+      tokAtE_t = __shfl(te, je);  // an E_EOT precedes a token end at its own position
+    }
     const uint32_t RatE = haveE ? RatE_t : cLastER;
     const uint32_t byteAtE = haveE ? byteAtE_t : cLastEByte;
     const uint32_t tokAtPrevE = haveE ? tokAtE_t : cTokAtLastE;
@@ -1502,7 +1508,8 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
     const unsigned long long mSTART = __ballot(f & EV_TOK_START);
     const unsigned long long mPrevStart = mSTART & lt;
     const int js = mPrevStart ? highest(mPrevStart) : 0;
-    const uint32_t startP_t = __shfl(P, js), startR_t = __shfl(R, js);
+    uint32_t startP_t = 0, startR_t = 0;
+    if (mSTART) { startP_t = __shfl(P, js); startR_t = __shfl(R, js); }  // wave-uniform: tokens of 31 bytes and more
     uint32_t startP = mPrevStart ? startP_t : cStartP;
     uint32_t startR = mPrevStart ? startR_t : cStartR;
     if (isEnd && lenf < EV_LEN_LONG) {
@@ -1591,7 +1598,7 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
       cSEatEnd = __shfl(eBeforeEnd + sBeforeEnd, jl);
       cEatEnd = __shfl(eBeforeEnd, jl);
       cLastEndR = __shfl(R, jl);
-      cLastEndByte = __shfl(tb, jl);
+      cLastEndByte = nl_rule ? __shfl(tb, jl) : 0u;
       cLastRend = __shfl(rend, jl);
       cBase = __shfl(tbase, jl);
     }
