@@ -1110,17 +1110,21 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
     return hip_fail(hipGetLastError(), "symbolize");
   STAGE(2);
   DtkWalkArgs w = walk_args(b);
+  bool fix_in_scan = false;
+  DtkSpecArgs sp_first{};
   if (b->chunk == 0) {
     STAGE(3); STAGE(4);
     if (dtk_launch_walk(&m->tab, &w, s)) return hip_fail(hipGetLastError(), "walk");
     STAGE(5); STAGE(6); STAGE(7);
   } else {
     DtkSpecArgs sp = spec_args(b, false);
+    sp_first = sp;
     uint32_t *n_bad = (uint32_t *)(b->d_totals + 5);
     // DATOK_SPLIT_START=1: start records and chunk walk as two launches (the repair rounds' kernels)
     static const bool split = getenv("DATOK_SPLIT_START") && atoi(getenv("DATOK_SPLIT_START")) != 0;
+    fix_in_scan = b->n_docs <= 8192u;  // k_spec_fix's step rides in the one-block scan kernel
     for (int stage = 0; stage < 5; stage++) {
-      if (((skip & 2) && stage <= 1) || ((skip & 4) && stage == 2)) { STAGE(3 + stage); continue; }
+      if (((skip & 2) && stage <= 1) || ((skip & 4) && stage == 2) || (stage == 4 && fix_in_scan)) { STAGE(3 + stage); continue; }
       // one launch for start records + walk (timed as "walk"); the link pass, which only reads the
       // records, then runs in front of the verification
       const int what = split ? stage : (stage <= 1 ? -1 : stage == 2 ? 6 : stage);
@@ -1139,7 +1143,8 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
   c.totals = b->d_totals;
   // rows are sized by the walk's own counts (no counting pass)
   if (dtk_launch_scan3(b->d_tok_cnt, b->d_sent_cnt, b->d_text_cnt, b->d_tok_off, b->d_sent_off, b->d_text_off,
-                       b->n_docs, b->d_totals, b->d_status, b->d_scan_ws, s))
+                       b->n_docs, b->d_totals, b->d_status, b->d_scan_ws, fix_in_scan ? &sp_first : nullptr, b->d_redo,
+                       (uint32_t *)(b->d_totals + 5), s))
     return hip_fail(hipGetLastError(), "scan");
   STAGE(8);
   b->last_args = c;
@@ -1205,7 +1210,7 @@ static int finish(dtk_batch *b) {
       if (b->repair_rounds > 1000000u) return DTK_E_STATE;
     }
     if (dtk_launch_scan3(b->d_tok_cnt, b->d_sent_cnt, b->d_text_cnt, b->d_tok_off, b->d_sent_off, b->d_text_off,
-                       b->n_docs, b->d_totals, b->d_status, b->d_scan_ws, s))
+                       b->n_docs, b->d_totals, b->d_status, b->d_scan_ws, nullptr, nullptr, nullptr, s))
       return hip_fail(hipGetLastError(), "scan");
     int rc = launch_compact2(b);
     if (rc != DTK_OK) return rc;

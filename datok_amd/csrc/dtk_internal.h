@@ -244,7 +244,7 @@ uint32_t dtk_render_tiles(uint64_t n);
 int dtk_launch_clear2(void *a, uint64_t a_bytes, void *b, uint64_t b_bytes, void *stream);
 int dtk_launch_scan3(const uint64_t *ca, const uint64_t *cb, const uint64_t *cc, uint64_t *a, uint64_t *b,
                      uint64_t *c, uint32_t n_docs, uint64_t *totals, const uint32_t *status, uint64_t *ws,
-                     void *stream);
+                     const struct DtkSpecArgs *fix_spec, uint32_t *redo_out, uint32_t *n_bad, void *stream);
 #ifdef __cplusplus
 }
 #endif

@@ -1737,36 +1737,51 @@ __global__ __launch_bounds__(WAVE) void k_seg_scan(DtkCompactArgs A, const uint3
 // counts flagged documents.  One 1024-thread block; each thread
 // owns a contiguous slice, a block-level scan links the slices.
 
+// One block: per-document counts -> CSR offsets (three arrays) + the number of flagged documents.
+// Each thread adds up a few consecutive documents, the 16 waves scan with shuffles, one barrier
+// links them.  With `fix` set it also does k_spec_fix's per-document step (one launch less on the
+// batch's critical path).
 __global__ __launch_bounds__(1024) void k_scan3(const uint64_t *ca, const uint64_t *cb, const uint64_t *cc,
                                                 uint64_t *a, uint64_t *b, uint64_t *c, uint32_t n,
-                                                uint64_t *totals, const uint32_t *status) {
-  __shared__ uint64_t sh[3][1024];
-  __shared__ uint32_t shf[1024];
-  const uint32_t T = blockDim.x, tid = threadIdx.x;
+                                                uint64_t *totals, const uint32_t *status, DtkSpecArgs S,
+                                                uint32_t *redo_out, uint32_t *n_bad, int fix) {
+  __shared__ uint64_t wsum[3][16];
+  __shared__ uint32_t wfl[16];
+  const uint32_t T = blockDim.x, tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
   const uint32_t per = (n + T - 1) / T;
   const uint32_t lo = tid * per < n ? tid * per : n;
   const uint32_t hi = lo + per < n ? lo + per : n;
   uint64_t sa = 0, sb = 0, sc = 0;
   uint32_t fl = 0;
-  for (uint32_t i = lo; i < hi; i++) { sa += ca[i]; sb += cb[i]; sc += cc[i]; fl += status[i] != 0; }
-  sh[0][tid] = sa; sh[1][tid] = sb; sh[2][tid] = sc; shf[tid] = fl;
-  __syncthreads();
-  for (uint32_t o = 1; o < T; o <<= 1) {
-    uint64_t xa = 0, xb = 0, xc = 0; uint32_t xf = 0;
-    if (tid >= o) { xa = sh[0][tid - o]; xb = sh[1][tid - o]; xc = sh[2][tid - o]; xf = shf[tid - o]; }
-    __syncthreads();
-    sh[0][tid] += xa; sh[1][tid] += xb; sh[2][tid] += xc; shf[tid] += xf;
-    __syncthreads();
+  for (uint32_t i = lo; i < hi; i++) {
+    sa += ca[i]; sb += cb[i]; sc += cc[i]; fl += status[i] != 0;
+    if (fix) {
+      const uint32_t bad = ~S.fail_lane[i];
+      if (bad == 0xFFFFFFFFu) redo_out[i] = 0xFFFFFFFFu; else mark_redo(S, i, bad, redo_out, n_bad);
+    }
   }
-  uint64_t ra = sh[0][tid] - sa, rb = sh[1][tid] - sb, rc = sh[2][tid] - sc;
+  uint64_t xa = sa, xb = sb, xc = sc;
+  uint32_t xf = fl;
+#pragma unroll
+  for (int o = 1; o < WAVE; o <<= 1) {
+    const uint64_t ya = __shfl_up(xa, o), yb = __shfl_up(xb, o), yc = __shfl_up(xc, o);
+    const uint32_t yf = __shfl_up(xf, o);
+    if ((int)lane >= o) { xa += ya; xb += yb; xc += yc; xf += yf; }
+  }
+  if (lane == WAVE - 1) { wsum[0][wid] = xa; wsum[1][wid] = xb; wsum[2][wid] = xc; wfl[wid] = xf; }
+  __syncthreads();
+  uint64_t ba = 0, bb = 0, bc = 0;
+  uint32_t bf = 0;
+  for (uint32_t w = 0; w < wid; w++) { ba += wsum[0][w]; bb += wsum[1][w]; bc += wsum[2][w]; bf += wfl[w]; }
+  uint64_t ra = ba + xa - sa, rb = bb + xb - sb, rc = bc + xc - sc;
   for (uint32_t i = lo; i < hi; i++) {
     a[i] = ra; b[i] = rb; c[i] = rc;
     ra += ca[i]; rb += cb[i]; rc += cc[i];
   }
   if (tid == T - 1) {
-    a[n] = sh[0][tid]; b[n] = sh[1][tid]; c[n] = sh[2][tid];
-    totals[0] = sh[0][tid]; totals[1] = sh[1][tid]; totals[2] = sh[2][tid];
-    totals[3] = shf[tid];
+    a[n] = ba + xa; b[n] = bb + xb; c[n] = bc + xc;
+    totals[0] = ba + xa; totals[1] = bb + xb; totals[2] = bc + xc;
+    totals[3] = bf + xf;
   }
 }
 
@@ -2005,13 +2020,19 @@ __global__ __launch_bounds__(SCAN_TB) void k_scan3_apply(const uint64_t *ca, con
   }
 }
 
+// fix_spec != nullptr: also k_spec_fix's per-document step (only done in the one-block case: returns 1 if it was)
 extern "C" int dtk_launch_scan3(const uint64_t *ca, const uint64_t *cb, const uint64_t *cc, uint64_t *a,
                                 uint64_t *b, uint64_t *c, uint32_t n_docs, uint64_t *totals,
-                                const uint32_t *status, uint64_t *ws, void *stream) {
+                                const uint32_t *status, uint64_t *ws, const DtkSpecArgs *fix_spec,
+                                uint32_t *redo_out, uint32_t *n_bad, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   if (n_docs <= 8192u || !ws) {
-    hipLaunchKernelGGL(k_scan3, dim3(1), dim3(1024), 0, s, ca, cb, cc, a, b, c, n_docs, totals, status);
+    DtkSpecArgs none{};
+    // 1024 threads: the kernel's time is the threads' serial loops over their documents (512: +50 %)
+    hipLaunchKernelGGL(k_scan3, dim3(1), dim3(1024), 0, s, ca, cb, cc, a, b, c, n_docs, totals, status,
+                       fix_spec ? *fix_spec : none, redo_out, n_bad, fix_spec ? 1 : 0);
   } else {
+    if (fix_spec) return -1;  // the caller runs k_spec_fix itself for that many documents
     const uint32_t nb = (n_docs + SCAN_TILE - 1) / SCAN_TILE;
     hipLaunchKernelGGL(k_scan3_sums, dim3(nb), dim3(SCAN_TB), 0, s, ca, cb, cc, status, n_docs, ws);
     hipLaunchKernelGGL(k_scan3_mid, dim3(1), dim3(SCAN_TB), 0, s, ws, nb, a, b, c, n_docs, totals);
