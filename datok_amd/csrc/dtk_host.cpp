@@ -166,12 +166,15 @@ static int upload(dtk_model *m, const void *tab, size_t tab_bytes) {
   HIP_TRY(hipMemcpy(m->d_tab, tab, tab_bytes, hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc((void **)&m->d_ascii, 256 * sizeof(uint16_t)));
   HIP_TRY(hipMemcpy(m->d_ascii, m->ascii, 256 * sizeof(uint16_t), hipMemcpyHostToDevice));
-  const size_t nr = m->sigma_runes.size();
+  // the device's sorted rune list only holds runes >= 256 (the others go through the 256-entry table)
+  size_t first = 0;
+  while (first < m->sigma_runes.size() && m->sigma_runes[first] < 256u) first++;
+  const size_t nr = m->sigma_runes.size() - first;
   HIP_TRY(hipMalloc((void **)&m->d_runes, std::max<size_t>(nr, 1) * sizeof(uint32_t)));
   HIP_TRY(hipMalloc((void **)&m->d_syms, std::max<size_t>(nr, 1) * sizeof(uint16_t)));
   if (nr) {
-    HIP_TRY(hipMemcpy(m->d_runes, m->sigma_runes.data(), nr * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(m->d_syms, m->sigma_syms.data(), nr * sizeof(uint16_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(m->d_runes, m->sigma_runes.data() + first, nr * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(m->d_syms, m->sigma_syms.data() + first, nr * sizeof(uint16_t), hipMemcpyHostToDevice));
   }
   m->device_bytes = tab_bytes + 512 + nr * 6;
   m->sig.ascii = m->d_ascii;

@@ -84,6 +84,7 @@ __device__ __forceinline__ uint32_t doc_of(const uint64_t *__restrict__ doc_off,
 
 #define SYM_BLOCK_BYTES DTK_SYM_BLOCK_BYTES
 #define SYM_TILE 512u
+#define SYM_SIG_LDS 64u  // runes >= 256 of the sigma kept in LDS (40 in the shipped models)
 #define SYM_HALF 1024u  // the heavy pass runs once per this many bytes (its queue: 2 B of LDS per byte)
 
 template <bool ALIGNED4>
@@ -97,12 +98,12 @@ __global__ __launch_bounds__(WAVE) void k_symbolize(const uint8_t *__restrict__ 
   __shared__ uint32_t s_rs[SYM_BLOCK_BYTES / 32];  // bit i: byte i of the block starts a rune
   __shared__ uint16_t lut[128];       // symbol | class | START for the runes < 128 (index = byte)
   __shared__ uint16_t lat[256];       // symbol | class for runes < 256 (heavy path, Latin-1)
-  __shared__ uint32_t s_runes[256];   // sigma map (runes >= 256)
-  __shared__ uint16_t s_syms[256];
+  __shared__ uint32_t s_runes[SYM_SIG_LDS];   // sigma map (runes >= 256), if it fits
+  __shared__ uint16_t s_syms[SYM_SIG_LDS];
   __shared__ uint32_t s_txt[SYM_BLOCK_BYTES / 4 + 4];  // the block's bytes, one dword of halo either side
   __shared__ uint16_t s_q[SYM_HALF];  // positions (offset in the block) of the bytes >= 0x80 of one half
   const uint32_t lane = threadIdx.x;
-  const bool sig_lds = sig.n_runes <= 256u;
+  const bool sig_lds = sig.n_runes <= SYM_SIG_LDS;
   for (uint32_t i = lane; i < SYM_BLOCK_BYTES / 32; i += WAVE) s_rs[i] = 0;
   for (uint32_t i = lane; i < 256u; i += WAVE) {
     // matrix.go:421-426: runes < 256 go through sigmaASCII; rune 4 is EOT
@@ -1313,7 +1314,8 @@ __device__ __forceinline__ bool seg_range(const DtkCompactArgs &A, uint32_t s, u
 }
 
 __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
-  __shared__ uint32_t qpos[CQ_CAP], qfl[CQ_CAP], qrn[CQ_CAP];
+  __shared__ uint32_t qpos[CQ_CAP], qrn[CQ_CAP];
+  __shared__ uint16_t qfl[CQ_CAP];  // 8 event bits + 5 bits of token length
   const bool seg_mode = A.seg_doc != nullptr;
   if (blockIdx.x >= (seg_mode ? A.n_segs : A.n_docs)) return;
   const uint32_t d = seg_mode ? A.seg_doc[blockIdx.x] : blockIdx.x;
@@ -1426,7 +1428,7 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
       if (evn & (1u << j)) {
         const uint32_t at = slot & (CQ_CAP - 1u);
         qpos[at] = P0 + j;
-        qfl[at] = ((fw >> (8 * j)) & 0xFFu) | (((lw >> (8 * j)) & 0x1Fu) << 8);
+        qfl[at] = (uint16_t)(((fw >> (8 * j)) & 0xFFu) | (((lw >> (8 * j)) & 0x1Fu) << 8));
         qrn[at] = Rl + (uint32_t)__popc(rsn & ((1u << j) - 1u));
         slot++;
       }
