@@ -46,17 +46,18 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total) 
 
 // ---------------------------------------------------------------- symbolise
 //
-// One wave per 4 KiB of input, 256 bytes (4 per lane) per iteration.
-//   light: every byte < 0x80 is a complete rune: its entry comes from a 256-entry
-//          table in LDS.  Positions holding a byte >= 0x80 (a few percent of
-//          European text) are appended to a small queue in LDS.
-//   heavy: lane i takes the i-th queued position and decodes it with Go's
+// One wave per 4 KiB of input (staged in LDS), 512 bytes (8 per lane) per iteration.
+//   light: every byte < 0x80 is a complete rune: its entry comes from a 128-entry
+//          table in LDS and the lane's 8 entries leave as one 16-byte store.  Positions
+//          holding a byte >= 0x80 (a few percent of European text) are appended to a
+//          queue in LDS.
+//   heavy: once per KiB, lane i takes the i-th queued position, decodes it with Go's
 //          DecodeRune rules (matrix.go:392), decides whether that byte really
-//          starts a rune (look-back of up to 3 bytes) and looks the rune up in
-//          the sigma map (also in LDS).  Documents never share a rune: look-back
+//          starts a rune (look-back of up to 3 bytes), looks the rune up in the sigma
+//          map (runes < 256: a table; the others: binary search, both in LDS) and
+//          overwrites that one entry.  Documents never share a rune: look-back
 //          and look-ahead stop at the document boundary (reader EOF,
 //          matrix.go:394-399).
-// The 256 entries of the iteration are assembled in LDS and leave as 8-byte stores.
 
 // width Go's DecodeRune reports at a position (b0 first byte, `avail` bytes left in the
 // document).  Integer predicates on purpose: bool && chains become branches.
