@@ -20,7 +20,7 @@ EXPORTS = [
     "dtk_model_load", "dtk_model_load_mem", "dtk_model_free", "dtk_model_type", "dtk_model_get_info",
     "dtk_batch_create", "dtk_batch_free", "dtk_batch_set_input", "dtk_batch_set_input_device",
     "dtk_batch_run", "dtk_batch_sync", "dtk_batch_stream", "dtk_batch_totals",
-    "dtk_batch_set_profiling", "dtk_batch_stage_ms", "dtk_batch_set_chunking",
+    "dtk_batch_set_profiling", "dtk_batch_stage_ms", "dtk_batch_set_chunking", "dtk_batch_set_warm_extend",
     "dtk_batch_result_device", "dtk_batch_result_host", "dtk_transduce", "dtk_free",
     "dtk_foma_to_matok", "dtk_transduce_replay", "dtk_batch_render_device", "dtk_batch_render_host",
     "dtk_batch_status_host", "dtk_transduce_release", "dtk_transduce_result",
@@ -114,6 +114,7 @@ def lib():
     L.dtk_batch_stream.argtypes = [vp]
     L.dtk_batch_totals.argtypes = [vp, C.POINTER(Totals)]
     L.dtk_batch_set_chunking.argtypes = [vp, u32, u32]
+    L.dtk_batch_set_warm_extend.argtypes = [vp, u32]
     L.dtk_batch_set_profiling.argtypes = [vp, C.c_int]
     L.dtk_batch_stage_ms.argtypes = [vp, C.POINTER(C.c_float * 9)]
     L.dtk_batch_result_device.argtypes = [vp, C.POINTER(ResultView)]

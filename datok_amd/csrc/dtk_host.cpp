@@ -705,6 +705,7 @@ struct dtk_batch {
   // speculative chunk lanes
   std::vector<uint64_t> h_doc_off;   // host copy of the document offsets (lane planning)
   uint32_t cfg_chunk = 0xFFFFFFFFu;  // 0 = one lane per document, 0xFFFFFFFF = automatic
+  uint32_t cfg_extend = 240;         // move the warm-up start back to the previous blank, at most this far
   uint32_t cfg_warm = 48;            // longer than almost every token; a miss only costs a repair round
   uint32_t chunk = 0;                // chunk size of the current plan (0 = none)
   bool plan_valid = false;
@@ -906,6 +907,12 @@ extern "C" int dtk_batch_set_chunking(dtk_batch *b, uint32_t chunk_bytes, uint32
   return DTK_OK;
 }
 
+extern "C" int dtk_batch_set_warm_extend(dtk_batch *b, uint32_t max_bytes) {
+  if (!b) return DTK_E_ARG;
+  b->cfg_extend = max_bytes > 4096u ? 4096u : max_bytes;
+  return DTK_OK;
+}
+
 // Splits the documents into chunk lanes (host side of the speculative walk).
 static int plan_lanes(dtk_batch *b) {
   if (b->plan_valid) return DTK_OK;
@@ -1028,6 +1035,8 @@ static DtkSpecArgs spec_args(dtk_batch *b, bool redo) {
     s.warm_ws = e ? (uint32_t)atoi(e) : 0u;
     static const char *e2 = getenv("DATOK_WARM_MIN");
     s.warm_min = e2 ? (uint32_t)atoi(e2) : 0u;
+    static const char *e5 = getenv("DATOK_WARM_EXTEND");
+    s.warm_extend = e5 ? (uint32_t)atoi(e5) : b->cfg_extend;
     // Event bytes through LDS lists pay off when the batch's event arrays no longer fit the L2
     // (measured: +10 % at 256 MiB, +3..8 % at 64 MiB, -3 % at 16 MiB).  DATOK_EV_LISTS=0/1 forces, DATOK_EV_LISTS_MIN moves the limit.
     static const char *e3 = getenv("DATOK_EV_LISTS");
@@ -1200,6 +1209,7 @@ static int finish(dtk_batch *b) {
     while ((uint32_t)b->h_totals[5] != 0) {
       b->repair_rounds++;
       DtkSpecArgs sp = spec_args(b, true);
+      sp.first_repair = b->repair_rounds == 1u ? 1u : 0u;
       HIP_TRY(hipMemsetAsync(n_bad, 0, 8, s));
       // spread + reset, clear, then the stages of the first pass restricted to what is repaired
       if (dtk_launch_spec(&m->tab, &w, &sp, 5, cmp_mask_of(m), b->d_redo, n_bad, s) ||

@@ -121,7 +121,8 @@ struct DtkLaneCount {
   uint32_t status;
   // for compacting a long document in segments (k_seg_*): SentenceEnd calls, and the lane's last
   // TextEnd fired by an EOT: its position (0xFFFFFFFF = none) and the lane's Token calls before it
-  uint32_t sev, e_pos, e_tok, pad;
+  uint32_t sev, e_pos, e_tok;
+  uint32_t pad;  // the closing byte the lane stopped with (k_redo_reset puts it back in the first repair round)
 };
 struct DtkSpecArgs {
   uint32_t n_lanes;
@@ -138,6 +139,8 @@ struct DtkSpecArgs {
   const uint8_t *text;              // input bytes (k_spec_start: whitespace-guided warm-up), or null
   uint32_t warm_ws;                 // start the warm-up behind the warm_ws-th whitespace run before the chunk (0: fixed)
   uint32_t warm_min;                // ... looking backwards from chunk start - warm_min
+  uint32_t first_repair;            // repair rounds: 1 in the round that follows the first pass
+  uint32_t warm_extend;             // move the warm-up start back to the previous blank, at most this many bytes (0: off)
   uint32_t ev_lists;                // lean walk: collect event bytes in LDS lists (large batches), 0: plain stores
 };
 

@@ -407,12 +407,13 @@ struct EventSink {
   uint32_t c_tok, c_sent, c_text;
   uint32_t c_sev;         // SentenceEnd calls (all of them, also where the reference would panic)
   uint32_t e_pos, e_tok;  // the last EOT TextEnd of this lane: position, Token calls before it
+  uint32_t last_c;        // the last closing byte of this lane (the one at the position where it stops)
   __device__ __forceinline__ void init(uint8_t *a, uint8_t *b, uint32_t wlo, uint32_t whi,
                                        uint32_t *list = nullptr) {
     evA = a; dB = (uint64_t)(b - a); lo = wlo; hi = whi; elist = list; ecount = 0;
     last_s_p = last_eot_p = 0xFFFFFFFFu; s_bits = eot_bits = 0; st = 0; dropped = 0;
     c_tok = c_sent = c_text = 0;
-    c_sev = 0; e_pos = 0xFFFFFFFFu; e_tok = 0;
+    c_sev = 0; e_pos = 0xFFFFFFFFu; e_tok = 0; last_c = 0;
   }
   // writes the listed bytes; lanes of a wave call it together (the loop runs to the longest list)
   __device__ __forceinline__ void flush() {
@@ -450,7 +451,8 @@ struct EventSink {
     // more additionally marks its start in the opening byte of its first position (a SentenceEnd
     // may have fired at that cursor before: same byte, stored by this lane)
     const uint32_t bl = p - tp;
-    put(0u, p, bits | ((bl < EV_LEN_LONG ? bl : EV_LEN_LONG) << EV_LEN_SHIFT));
+    last_c = bits | ((bl < EV_LEN_LONG ? bl : EV_LEN_LONG) << EV_LEN_SHIFT);
+    put(0u, p, last_c);
     if (bl >= EV_LEN_LONG) put(1u, tp, EV_TOK_START | (tp == last_s_p ? s_bits : 0u));
   }
   // SentenceEnd? + TextEnd fired by an EOT rune -- matrix.go:593-600
@@ -465,6 +467,7 @@ struct EventSink {
     if (!IS_MATRIX && p == last_eot_p) st |= ST_IRREGULAR;  // the same EOT consumed twice
     const uint32_t bits = EV_E_EOT | (with_sentence ? EV_S_EOT : 0u);
     if (!IS_MATRIX) { last_eot_p = p; eot_bits = bits; }
+    last_c = bits;
     put(0u, p, bits);
   }
   // SentenceEnd from an epsilon arc on an empty token -- matrix.go:574-575
@@ -987,6 +990,45 @@ __device__ __forceinline__ DtkLaneState start_record(const TRANS &tr, const DtkW
       }
       sp = q;  // first byte of the run of blanks (the walk skips them), or the fixed start
     }
+    if (sp > 0 && S.warm_extend && S.text) {
+      // A start inside a long blank-free token (a URL, say) makes the warm-up invent token ends the
+      // real walk does not have -- a repair round.  Blanks are token boundaries in every tokenizer of
+      // this kind: move the start back to the previous blank (typically half a dozen bytes; at
+      // most warm_extend).
+      // (8 bytes per step: the dwords around them are read whole, a blank is found with byte-wise
+      // zero tests on  bytes ^ pattern)
+      const uint8_t *tx = S.text + off;
+      const uint32_t lim = sp > S.warm_extend ? sp - S.warm_extend : 0u;
+      uint32_t q = sp;
+      while (q > lim) {
+        // bytes tx[q-8 .. q-1] as one 64-bit word, tx[q-1] on top
+        uint64_t w;
+        if (off + q >= 16u) {
+          const uint64_t a0 = reinterpret_cast<uint64_t>(tx + q) - 8u;  // address of the first of the 8 bytes
+          const uint32_t sh = (uint32_t)(a0 & 3u) * 8u;
+          const uint32_t *wp = reinterpret_cast<const uint32_t *>(a0 & ~3ull);
+          const uint64_t lo64 = (uint64_t)wp[0] | ((uint64_t)wp[1] << 32);
+          w = sh ? (lo64 >> sh) | ((uint64_t)wp[2] << (64u - sh)) : lo64;
+        } else {  // the first bytes of the batch: one by one
+          w = 0;
+          for (uint32_t k = 0; k < 8u; k++)
+            if (q + k >= 8u) w |= (uint64_t)tx[q + k - 8u] << (8u * k);
+        }
+        auto zb = [](uint64_t x) {
+          return ~(((x & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | x) & 0x8080808080808080ull;
+        };
+        uint64_t m = zb(w ^ 0x2020202020202020ull) | zb(w ^ 0x0A0A0A0A0A0A0A0Aull) |
+                     zb(w ^ 0x0909090909090909ull) | zb(w ^ 0x0D0D0D0D0D0D0D0Dull);
+        if (q < 8u) m &= ~0ull << ((8u - q) * 8u);  // bytes before the document do not count
+        if (m) {  // start behind the last blank
+          q = q - 8u + (7u - ((uint32_t)__clzll((long long)m) >> 3)) + 1u;
+          break;
+        }
+        q = q >= 8u ? q - 8u : 0u;
+      }
+      if (q < lim) q = lim;
+      sp = q;
+    }
     EventSink sink;
     sink.init(nullptr, nullptr, 0u, 0u);
     uint32_t st;
@@ -1046,8 +1088,13 @@ __global__ __launch_bounds__(WAVE) void k_spec_both(TRANS tr, DtkWalkArgs A, Dtk
     S.lane_start[L] = rec;
     DtkLaneState fin{0xFFFFFFFFu, 0u, 0u, LANE_F_IDLE};
     DtkLaneCount cnt{0u, 0u, 0u, 0u, 0u, 0xFFFFFFFFu, 0u, 0u};
-    if (rec.p != 0xFFFFFFFFu) {
-      const uint32_t stop = (L + 1u < S.chunk_off[d + 1]) ? (k + 1u) * S.chunk : 0xFFFFFFFFu;
+    const uint32_t stop = (L + 1u < S.chunk_off[d + 1]) ? (k + 1u) * S.chunk : 0xFFFFFFFFu;
+    if (rec.p != 0xFFFFFFFFu && rec.p >= stop) {
+      // my first sync point lies behind my whole chunk (a token longer than a chunk): it is my
+      // successor's record too, and I own nothing
+      fin = rec;
+      fin.flags &= (LANE_F_SENT | LANE_F_TEXT | LANE_F_OK);
+    } else if (rec.p != 0xFFFFFFFFu) {
       EventSink sink;
       const uint64_t evb = DTK_EV_BASE(off, d);
       sink.init(A.evA + evb, A.evB + evb, rec.p, 0xFFFFFFFFu, el_row);
@@ -1057,7 +1104,7 @@ __global__ __launch_bounds__(WAVE) void k_spec_both(TRANS tr, DtkWalkArgs A, Dtk
       steps += steps2;
       if (sink.dropped) fin.flags |= LANE_F_DROPPED;
       cnt.tok = sink.c_tok; cnt.sent = sink.c_sent; cnt.text = sink.c_text; cnt.status = st | sink.st;
-      cnt.sev = sink.c_sev; cnt.e_pos = sink.e_pos; cnt.e_tok = sink.e_tok;
+      cnt.sev = sink.c_sev; cnt.e_pos = sink.e_pos; cnt.e_tok = sink.e_tok; cnt.pad = sink.last_c;
     }
     S.lane_end[L] = fin;
     S.lane_cnt[L] = cnt;
@@ -1121,7 +1168,12 @@ __global__ __launch_bounds__(WAVE) void k_spec_walk(TRANS tr, DtkWalkArgs A, Dtk
       const DtkLanePlan pl = plan_of(S, L, d);
       DtkLaneState fin{0xFFFFFFFFu, 0u, 0u, LANE_F_IDLE};
       DtkLaneCount cnt{0u, 0u, 0u, 0u, 0u, 0xFFFFFFFFu, 0u, 0u};
-      if (pl.mode != PLAN_OFF) {
+      const DtkLaneState init0 = pl.mode == PLAN_CHAINED ? S.lane_start[L] : DtkLaneState{0xFFFFFFFFu, 0u, 0u, 0u};
+      if (pl.mode == PLAN_CHAINED && init0.p != 0xFFFFFFFFu && init0.p >= pl.stop) {
+        // my record is my successor's too (a token longer than a chunk): nothing of it is mine
+        fin = init0;
+        fin.flags &= (LANE_F_SENT | LANE_F_TEXT | LANE_F_OK);
+      } else if (pl.mode != PLAN_OFF) {
         const uint64_t off = A.doc_off[d];
         const uint32_t len = (uint32_t)(A.doc_off[d + 1] - off);
         const DtkLaneState init = S.lane_start[L];
@@ -1133,7 +1185,7 @@ __global__ __launch_bounds__(WAVE) void k_spec_walk(TRANS tr, DtkWalkArgs A, Dtk
                                                 identity, step_cap(A.step_factor, len), fin, st, steps, win_row);
         if (sink.dropped) fin.flags |= LANE_F_DROPPED;
         cnt.tok = sink.c_tok; cnt.sent = sink.c_sent; cnt.text = sink.c_text; cnt.status = st | sink.st;
-        cnt.sev = sink.c_sev; cnt.e_pos = sink.e_pos; cnt.e_tok = sink.e_tok;
+        cnt.sev = sink.c_sev; cnt.e_pos = sink.e_pos; cnt.e_tok = sink.e_tok; cnt.pad = sink.last_c;
       }
       S.lane_end[L] = fin;
       S.lane_cnt[L] = cnt;
@@ -1252,6 +1304,23 @@ __global__ __launch_bounds__(256) void k_redo_spread(DtkSpecArgs S) {
   }
 }
 
+// First position whose event bytes a repair of document d from lane `bad` on must clear: the bad
+// lane's start record -- except in the first repair round.  In the first pass every lane with a
+// record has walked, also the lanes behind the broken link, from their own (wrong) records; those
+// lie at or behind the end of the bad lane's chunk, but can lie BEFORE the bad lane's record when
+// that record is behind its whole chunk (a token longer than a chunk: the lane owns nothing).
+// The first round therefore clears from the end of the bad lane's chunk if that is lower: every
+// lane before the first bad one checked out, the one that walked up to `from` did not rewind
+// between the end of its own chunk and `from` (events only happen at rewinds), and the lanes
+// between it and the bad one own nothing.  Later rounds find no such leftovers (lanes behind the
+// link stay off in a repair walk), and lanes before the bad one may then own positions below
+// their successor's chunk end.
+__device__ __forceinline__ uint32_t redo_low(const DtkSpecArgs &S, uint32_t d, uint32_t bad, uint32_t from) {
+  if (!S.first_repair) return from;
+  const unsigned long long chunk_end = (unsigned long long)(bad - S.chunk_off[d] + 1u) * S.chunk;
+  return chunk_end < from ? (uint32_t)chunk_end : from;
+}
+
 __global__ __launch_bounds__(256) void k_redo_reset(DtkWalkArgs A, DtkSpecArgs S) {
   const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d >= A.n_docs || S.redo_from[d] == 0xFFFFFFFFu) return;
@@ -1260,10 +1329,21 @@ __global__ __launch_bounds__(256) void k_redo_reset(DtkWalkArgs A, DtkSpecArgs S
   // the slot behind the last byte (k_redo_clear covers the positions that are bytes)
   const uint64_t off = A.doc_off[d];
   const uint32_t len = (uint32_t)(A.doc_off[d + 1] - off);
-  const uint32_t from = S.lane_start[S.redo_from[d]].p;
+  const uint32_t bad = S.redo_from[d];
+  const uint32_t from = S.lane_start[bad].p, low = redo_low(S, d, bad, from);
   const uint64_t evb = DTK_EV_BASE(off, d);
-  if (len >= from) A.evB[evb + len] = 0;
+  if (len >= low) A.evB[evb + len] = 0;
   if (len > from) A.evA[evb + len] = 0;
+  // First repair round: the closing byte at `from` belongs to the last lane before `bad` that owns
+  // anything (it stopped there), but a lane behind the link, walking from a wrong record, may have
+  // ended a token of its own at the same position in the first pass -- one byte, two writers.
+  // Put the owner's byte back (every lane keeps the closing byte it stopped with).
+  const uint32_t L0 = S.chunk_off[d];
+  if (S.first_repair && bad > L0 && from != 0xFFFFFFFFu && from <= len) {
+    uint32_t o = bad - 1u;
+    while (o > L0 && S.lane_end[o].p == S.lane_start[o].p) o--;  // lanes in between own nothing
+    if (S.lane_end[o].p == from && S.lane_start[o].p != from) A.evA[evb + from] = (uint8_t)S.lane_cnt[o].pad;
+  }
 }
 
 // one block per DTK_SYM_BLOCK_BYTES input bytes; blk_doc[b] = document of the block's first byte
@@ -1279,10 +1359,10 @@ __global__ __launch_bounds__(256) void k_redo_clear(DtkWalkArgs A, DtkSpecArgs S
     const uint32_t bad = S.redo_from[d];
     if (bad == 0xFFFFFFFFu) continue;
     const uint64_t off = A.doc_off[d];
-    const uint32_t p = (uint32_t)(g - off), from = S.lane_start[bad].p;
+    const uint32_t p = (uint32_t)(g - off), from = S.lane_start[bad].p, low = redo_low(S, d, bad, from);
     const uint64_t evb = DTK_EV_BASE(off, d);
-    if (p >= from) A.evB[evb + p] = 0;
-    if (p > from) A.evA[evb + p] = 0;  // the closing byte at `from` belongs to the lane before
+    if (p >= low) A.evB[evb + p] = 0;
+    if (p > low && p != from) A.evA[evb + p] = 0;  // the closing byte at `from` belongs to the lane before
   }
 }
 

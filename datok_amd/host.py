@@ -307,9 +307,13 @@ class Batch:
 
     AUTO_CHUNK = 0xFFFFFFFF
 
-    def set_chunking(self, chunk_bytes=AUTO_CHUNK, warm_bytes=48):
-        """0: one lane per document; otherwise speculative chunk lanes (exact either way)."""
+    def set_chunking(self, chunk_bytes=AUTO_CHUNK, warm_bytes=48, extend=None):
+        """0: one lane per document; otherwise speculative chunk lanes (exact either way).
+        extend: how far the warm-up start may move back to the previous blank (None: library default,
+        0: fixed distance only -- what tests use to force mispredictions)."""
         check(lib().dtk_batch_set_chunking(self._h, int(chunk_bytes), int(warm_bytes)), "dtk_batch_set_chunking")
+        if extend is not None:
+            check(lib().dtk_batch_set_warm_extend(self._h, int(extend)), "dtk_batch_set_warm_extend")
 
     def set_profiling(self, enable=True):
         check(lib().dtk_batch_set_profiling(self._h, int(bool(enable))), "dtk_batch_set_profiling")

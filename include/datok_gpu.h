@@ -128,6 +128,12 @@ int dtk_batch_set_input_device(dtk_batch *b, const void *d_text, const void *d_d
  * the batch size.  warm_bytes defaults to 48. */
 int dtk_batch_set_chunking(dtk_batch *b, uint32_t chunk_bytes, uint32_t warm_bytes);
 
+/* A speculative start that falls inside a long blank-free token (a URL) would invent
+ * token ends; the start is therefore moved back from chunk - warm_bytes to the previous
+ * blank, by at most max_bytes (default 240; 0 = keep the fixed distance, which tests use
+ * to force mispredictions).  Speed only: the result is exact either way. */
+int dtk_batch_set_warm_extend(dtk_batch *b, uint32_t max_bytes);
+
 /* Launches the whole path on the batch's stream (asynchronous):
  * symbolise -> walk -> count -> scan -> compact.  flags: DTK_NEWLINE_AFTER_EOT
  * is the only bit that changes the numbers (token_writer.go:66-68); DTK_OFFSETS_ONLY

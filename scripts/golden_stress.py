@@ -46,7 +46,7 @@ for model in ("tokenizer_de.matok", "tokenizer_en.matok"):
     for chunk, warm in ((None, 48), (128, 32), (128, 24), (128, 16), (128, 64)):
         with datok_amd.Batch(len(text), n_docs) as b:
             if chunk is not None:
-                b.set_chunking(chunk, warm)
+                b.set_chunking(chunk, warm, extend=int(os.environ.get('EXTEND', '240')))
             b.set_input(text, off)
             b.run(tok, 0)
             tot = b.totals()

@@ -9,7 +9,7 @@ text, _ = corpus.german_docs(4096, 4096, seed=3)
 off = np.array([0, len(text)], dtype=np.uint64)
 for warm in (48, 32, 16, 4, 0):
     with datok_amd.Batch(len(text), 1) as b:
-        b.set_chunking(128, warm)
+        b.set_chunking(128, warm, extend=0)
         b.set_input(text, off)
         b.run(tok, 0); b.sync(); b.totals()
         t0 = time.perf_counter()

@@ -37,7 +37,8 @@ def run_batch(tok, text, doc_off, flags=0, chunk=None, warm=64):
     import datok_amd
     with datok_amd.Batch(max(len(text), 1), len(doc_off) - 1) as b:
         if chunk is not None:
-            b.set_chunking(chunk, warm)
+            # short warm-ups are there to force mispredictions: no help from the previous blank then
+            b.set_chunking(chunk, warm, extend=0 if warm < 16 else None)
         b.set_input(text, doc_off)
         b.run(tok, flags)
         return b.result(), b.totals()
@@ -570,3 +571,45 @@ def test_kernel_variants_forced_by_environment(env, tmp_path):
     e = dict(os.environ); e.update(env)
     r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, env=e, timeout=600)
     assert r.returncode == 0 and b"VARIANT OK" in r.stdout, r.stderr.decode()[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["tokenizer_de.matok", "tokenizer_de.datok"])
+@pytest.mark.parametrize("chunk", [64, 128, 256])
+def test_tokens_longer_than_warmup_and_chunk(gpu, oracle_models, model, chunk):
+    """Blank-free tokens of 60..700 bytes (URLs, runs of letters): longer than the warm-up, and the longest longer
+    than several chunks, so that lanes exist whose whole chunk lies inside one token (they own nothing).  The start
+    of a warm-up inside such a token moves back to the previous blank; with that switched off the same inputs go
+    through repair rounds.  Offsets equal the oracle's either way."""
+    import datok_amd
+    from datok_amd import corpus
+    rng = np.random.default_rng(21)
+    text, off = corpus.german_docs(96, 4096, seed=21)
+    raw = bytearray(text.tobytes())
+    alpha = list(b"abcdefghijklmnopqrstuvwxyz0123456789/_-%")
+    for d in range(96):
+        p = d * 4096 + int(rng.integers(200, 1500))
+        for _ in range(3):
+            q = raw.find(b" ", p)
+            L = int(rng.choice([60, 90, 130, 200, 330, 700]))
+            if q < 0 or q + L + 2 >= (d + 1) * 4096 - 8:
+                break
+            body = bytes(rng.choice(alpha, size=L)) if rng.integers(0, 2) else b"x" * L
+            tok_bytes = (b"https://www.example.org/" + body)[:L]
+            raw[q + 1:q + 1 + L] = tok_bytes
+            raw[q + 1 + L] = 0x20
+            p = q + L + int(rng.integers(100, 600))
+    text = np.frombuffer(bytes(raw), dtype=np.uint8).copy()
+    tok, om = gpu(model), oracle_models(model)
+    rounds = {}
+    for extend in (240, 0):
+        with datok_amd.Batch(len(text), len(off) - 1) as b:
+            b.set_chunking(chunk, 48, extend=extend)
+            b.set_input(text, off)
+            b.run(tok, 0)
+            res, tot = b.result(), b.totals()
+            assert tot["n_flagged"] == 0
+            assert_batch_equals_oracle(om, res, text, off)
+            rounds[extend] = tot["repair_rounds"]
+    assert rounds[0] > 0  # the fixed distance does mispredict here
+    assert rounds[240] <= rounds[0]
