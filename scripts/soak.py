@@ -40,6 +40,27 @@ def random_docs(rng, n):
     return corpus.concat_docs(docs)
 
 
+def long_token_docs(rng, n):
+    """German text with blank-free tokens of 40..900 bytes (URLs, letter runs, digits): longer than the warm-up,
+    many longer than several chunks."""
+    text, off = corpus.german_docs(n, 4096, seed=int(rng.integers(0, 1 << 30)))
+    raw = bytearray(text.tobytes())
+    alpha = np.frombuffer(b"abcdefghijklmnopqrstuvwxyz0123456789/_-%.,:;?&=+#", dtype=np.uint8)
+    for d in range(n):
+        p = d * 4096 + int(rng.integers(0, 1500))
+        for _ in range(int(rng.integers(1, 6))):
+            q = raw.find(b" ", p)
+            L = int(rng.choice([40, 60, 90, 130, 200, 330, 500, 900]))
+            if q < 0 or q + L + 2 >= (d + 1) * 4096 - 8:
+                break
+            kind = int(rng.integers(0, 3))
+            body = bytes(rng.choice(alpha, size=L)) if kind == 0 else (b"x" * L if kind == 1 else b"0123456789" * (L // 10 + 1))
+            raw[q + 1:q + 1 + L] = ((b"https://www.example.org/" if kind == 0 else b"") + body)[:L]
+            raw[q + 1 + L] = 0x20
+            p = q + L + int(rng.integers(20, 600))
+    return np.frombuffer(bytes(raw), dtype=np.uint8).copy(), off
+
+
 def long_docs(rng, n):
     out = []
     for _ in range(n):
@@ -66,15 +87,18 @@ for seed in range(first, first + n_seeds):
              # a few long documents full of EOT texts, blanks and odd bytes: many compaction segments
              (str(rng.choice(["tokenizer_de.matok", "tokenizer_en.matok", "clitic_test.matok", "tokenizer_de.datok"])),
               long_docs(rng, int(rng.integers(1, 4)))),
+             # blank-free tokens longer than warm-up and chunks (empty lanes, repairs behind them)
+             (str(rng.choice(["tokenizer_de.matok", "tokenizer_de.datok", "tokenizer_en.matok"])), long_token_docs(rng, int(rng.integers(8, 48)))),
              # the double array on long documents without EOT (segments) 
              ("tokenizer_de.datok", corpus.german_docs(int(rng.integers(2, 6)), int(rng.choice([20000, 70000])), seed=seed + 3))]
     for name, (text, off) in cases:
         tok, om = models[name]
-        chunk, warm = [(None, 48), (0, 48), (64, 48), (128, 16), (256, 48), (48, 0), (1024, 48)][int(rng.integers(0, 7))]
+        chunk, warm = [(None, 48), (0, 48), (64, 48), (128, 16), (256, 48), (48, 0), (1024, 48), (64, 0), (128, 48)][int(rng.integers(0, 9))]
+        extend = [None, 0, 240, 16][int(rng.integers(0, 4))]
         flags = int(rng.choice([0, 16]))
         with datok_amd.Batch(max(len(text), 1), len(off) - 1) as b:
             if chunk is not None:
-                b.set_chunking(chunk, warm)
+                b.set_chunking(chunk, warm, extend=extend)
             b.set_input(text, off)
             b.run(tok, flags)
             res, tot = b.result(), b.totals()
