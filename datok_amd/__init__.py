@@ -17,7 +17,7 @@ HIP kernels behind the C-ABI of libdatok_gpu.so (include/datok_gpu.h):
     `datok convert` (matrix)             foma_to_matok(bytes) -> bytes        (cmd/datok.go:50-70)
     --                                   Batch: many documents per launch (addition)
 """
-from ._lib import (DatokGpuError, ST_BAD_MODEL, ST_EMPTY_TEXT, ST_IRREGULAR, ST_STEP_LIMIT,  # noqa: F401
+from ._lib import (DatokGpuError, ST_BAD_MODEL, ST_BAD_OFFSET, ST_EMPTY_TEXT, ST_IRREGULAR, ST_STEP_LIMIT,  # noqa: F401
                    ST_WINDOW_OVERFLOW, build, lib)
 from .host import (NEWLINE_AFTER_EOT, SENTENCE_POS, SENTENCES, SIMPLE, TOKEN_POS, TOKENS, Batch,  # noqa: F401
                    BatchResult, TokenWriter, Tokenizer, foma_to_matok, load_foma_file, load_tokenizer_file,

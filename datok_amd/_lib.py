@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("DATOK_GPU_LIB") or os.path.join(_HERE, "libdatok_gpu.
 # error codes / flags (datok_gpu.h)
 OK, E_IO, E_FORMAT, E_NO_DEVICE, E_HIP, E_ARG, E_MODEL, E_CAPACITY, E_STATE, E_NOMEM = 0, -1, -2, -3, -4, -5, -6, -7, -8, -9
 ST_WINDOW_OVERFLOW, ST_EMPTY_TEXT, ST_BAD_MODEL, ST_IRREGULAR, ST_STEP_LIMIT, ST_INTERNAL = 1, 2, 4, 8, 16, 32
+ST_BAD_OFFSET = 64
 
 EXPORTS = [
     "dtk_device_count", "dtk_set_device", "dtk_strerror", "dtk_last_hip_error",

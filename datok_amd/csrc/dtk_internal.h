@@ -57,6 +57,7 @@
 #define ST_BAD_MODEL 4u
 #define ST_IRREGULAR 8u
 #define ST_STEP_LIMIT 16u
+#define ST_BAD_OFFSET 64u  // Token call with its offset behind its buffer (the reference panics when it prints the surface)
 #define ST_INTERNAL 32u  // the walk's counts and the compaction disagree (a bug, never expected)
 
 struct DtkSigmaDev {

@@ -644,6 +644,7 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
       if (hardfail) {  // drop what is buffered as a token, restart at state 1
         if (is_eps) { st |= ST_BAD_MODEL; done = true; hardfail = false; }  // stale-buffer case
         else if (p <= tp) { p += w; }                                        // matrix.go:515-516
+        if (hardfail && p < tp) st |= ST_BAD_OFFSET;  // Token(bufft, buffer[:buffc]) with bufft > buffc
         t = t_start; aux = aux_start;                                        // matrix.go:548
       }
       if (my_steps > cap) { st |= ST_STEP_LIMIT; done = true; hardfail = false; }
@@ -840,6 +841,7 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
         if (r) { st |= ST_BAD_MODEL; done = true; }
         else {
           if (p <= tp) { p = pn; }  // matrix.go:515-516
+          if (p < tp) st |= ST_BAD_OFFSET;  // Token(bufft, buffer[:buffc]) with bufft > buffc
           else {  // the rune is read again
             uint32_t iw = p + o7 - wbase;
             if (iw >= DTK_WIN) { wbase = (p + o7) & ~7u; win_fill(row, aligned, wbase); iw = (p + o7) & 7u; }

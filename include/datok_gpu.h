@@ -64,7 +64,11 @@ enum {
   DTK_ST_IRREGULAR = 8,       /* >2 sentence ends at one cursor position, or a text end
                                  revisited (double array + in-document EOT backtrack) */
   DTK_ST_STEP_LIMIT = 16,     /* safety cap on lookups hit */
-  DTK_ST_INTERNAL = 32        /* internal consistency check failed (a bug; never expected) */
+  DTK_ST_INTERNAL = 32,       /* internal consistency check failed (a bug; never expected) */
+  DTK_ST_BAD_OFFSET = 64      /* a Token call whose offset lies behind its buffer (after a hard fail with the
+                                 epsilon slot behind the token start, e.g. "x ....\n\n" at the end of a document):
+                                 string(buf[offset:]) panics in the reference when surfaces are printed
+                                 (token_writer.go:85,93); in position-only modes it yields start > end */
 };
 
 typedef struct dtk_model dtk_model;

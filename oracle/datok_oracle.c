@@ -315,6 +315,7 @@ static void tw_token(void *ctx, int offset, const uint32_t *buf, int len,
                      const uint32_t *bstart, const uint8_t *bwidth) {
   twriter *w = (twriter *)ctx;
   (void)bstart; (void)bwidth;
+  if (offset > len && (w->flags & ORC_TOKENS)) w->status |= ORC_ST_BAD_OFFSET; /* string(buf[offset:]): slice bounds panic */
   if (w->flags & (ORC_TOKEN_POS | ORC_SENTENCE_POS)) { /* :49-88 */
     if (w->posC == 0 && (w->flags & ORC_NEWLINE_AFTER_EOT) && len > 0 && buf[0] == '\n' && !w->init)
       w->posC--; /* :66-68 */
@@ -386,6 +387,7 @@ typedef struct {
 static void cap_token(void *ctx, int offset, const uint32_t *buf, int len,
                       const uint32_t *bstart, const uint8_t *bwidth) {
   capture *c = (capture *)ctx;
+  if (offset > len) c->status |= ORC_ST_BAD_OFFSET; /* Go: slice bounds panic where the surface is printed */
   if (c->posC == 0 && (c->flags & ORC_NEWLINE_AFTER_EOT) && len > 0 && buf[0] == '\n' && !c->init)
     c->posC--;
   c->init = 0;
@@ -394,8 +396,13 @@ static void cap_token(void *ctx, int offset, const uint32_t *buf, int len,
   if (c->sentB) { c->sentB = 0; iv_push(&c->sent, c->posC); }
   c->posC += len - offset;
   iv_push(&c->rend, c->posC);
-  uv_push(&c->bstart, bstart[offset]);
-  uv_push(&c->bend, bstart[len - 1] + bwidth[len - 1]);
+  /* byte range of the surface buf[offset:len]; an empty surface (offset == len: the second Token
+     call for a document like "...\n") is the empty range at the end of the buffer */
+  {
+    const uint32_t bend = len > 0 ? bstart[len - 1] + bwidth[len - 1] : 0u;
+    uv_push(&c->bstart, offset < len ? bstart[offset] : bend);
+    uv_push(&c->bend, bend);
+  }
 }
 static void cap_sentence_end(void *ctx, int arg) {
   capture *c = (capture *)ctx;
@@ -428,7 +435,8 @@ static void ev_push(evec *v, orc_event e) {
 static void ev_token(void *ctx, int offset, const uint32_t *buf, int len,
                      const uint32_t *bstart, const uint8_t *bwidth) {
   (void)buf;
-  orc_event e = {0, offset, bstart[0], bstart[offset], bstart[len - 1] + bwidth[len - 1]};
+  const uint32_t bend_ = len > 0 ? bstart[len - 1] + bwidth[len - 1] : 0u;
+  orc_event e = {0, offset, len > 0 ? bstart[0] : 0u, offset < len ? bstart[offset] : bend_, bend_};
   ev_push((evec *)ctx, e);
 }
 static void ev_sentence_end(void *ctx, int arg) { orc_event e = {1, arg, 0, 0, 0}; ev_push((evec *)ctx, e); }

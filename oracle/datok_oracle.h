@@ -39,7 +39,9 @@ enum {
 enum {
   ORC_ST_WINDOW_OVERFLOW = 1, /* matrix.go:365,406 buffer[1024] index panic */
   ORC_ST_EMPTY_TEXT = 2,      /* token_writer.go:108,135,145 pos[-1]/pos[0] panic */
-  ORC_ST_BAD_MODEL = 4        /* walk left the table / would read stale buffer */
+  ORC_ST_BAD_MODEL = 4,       /* walk left the table / would read stale buffer */
+  ORC_ST_BAD_OFFSET = 64      /* Token(offset, buf) with offset > len(buf): string(buf[offset:]) panics
+                                 (token_writer.go:85,93); same bit as DTK_ST_BAD_OFFSET */
 };
 
 enum { ORC_KIND_MATRIX = 0, ORC_KIND_DA = 1 };

@@ -15,6 +15,7 @@ _LIB = os.path.join(_HERE, "liboracle.so")
 TOKENS, SENTENCES, TOKEN_POS, SENTENCE_POS, NEWLINE_AFTER_EOT = 1, 2, 4, 8, 16
 SIMPLE = TOKENS | SENTENCES
 ST_WINDOW_OVERFLOW, ST_EMPTY_TEXT, ST_BAD_MODEL = 1, 2, 4
+ST_BAD_OFFSET = 64
 
 
 def build(force=False):

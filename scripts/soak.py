@@ -27,9 +27,16 @@ def random_docs(rng, n):
     docs = []
     for _ in range(n):
         k = int(rng.integers(0, 600))
-        kind = rng.integers(0, 4)
+        kind = rng.integers(0, 6)
         if kind == 0:     # raw bytes, mostly invalid UTF-8
             docs.append(bytes(rng.integers(0, 256, size=k, dtype=np.uint8)))
+        elif kind == 4:   # runs of one character class, tokens up to and beyond the 1024-rune window
+            parts = []
+            while sum(map(len, parts)) < 3 * k:
+                c = str(rng.choice([".", "!", "a ", "1.", "\n", "x", "-", "ab", "\u00e4", "\u201e", ". ", "?!"]))
+                parts.append(c * int(rng.choice([1, 2, 5, 30, 64, 129, 400, 1020, 1100])))
+                parts.append(str(rng.choice(["", " ", "\n", " "])))
+            docs.append("".join(parts).encode())
         elif kind == 1:   # long tokens around the 31-byte length field
             parts = []
             while sum(map(len, parts)) < k:
@@ -105,7 +112,13 @@ for seed in range(first, first + n_seeds):
             irregular = {d for d in range(len(off) - 1) if res.status[d] & datok_amd.ST_IRREGULAR}
             assert not irregular or name.endswith(".datok"), (seed, name)
             keep = [d for d in range(len(off) - 1) if d not in irregular]
-            assert_batch_equals_oracle(om, res, text, off, flags, docs=keep)
+            try:
+                assert_batch_equals_oracle(om, res, text, off, flags, docs=keep)
+            except AssertionError:  # keep the failing batch for a closer look
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                np.savez(os.path.join(ROOT, "gpurun_out", "soak_fail.npz"), text=text, off=off, model=name, flags=flags,
+                         chunk=-1 if chunk is None else chunk, warm=warm, extend=-1 if extend is None else extend, seed=seed)
+                raise
             # and the rendered SIMPLE stream of a sample
             data, o = b.render(3 | flags)
             raw = text.tobytes()

@@ -613,3 +613,41 @@ def test_tokens_longer_than_warmup_and_chunk(gpu, oracle_models, model, chunk):
             rounds[extend] = tot["repair_rounds"]
     assert rounds[0] > 0  # the fixed distance does mispredict here
     assert rounds[240] <= rounds[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["tokenizer_de.matok", "tokenizer_en.matok", "tokenizer_de.datok"])
+def test_empty_second_token_of_a_dotted_line(gpu, oracle_models, model):
+    """A document that is nothing but full stops and a newline makes the reference emit a second Token call with
+    an empty surface (offset == len(buffer); rune offsets (n + 1, n + 1)).  Its byte range is the empty range at the
+    end of the document, for short and for long (31+ bytes: start mark + saturated length field) first tokens."""
+    from datok_amd import corpus
+    docs = [b"." * n + b"\n" for n in (1, 2, 3, 29, 30, 31, 40, 400)] + [b"Hi " + b"." * 40 + b"\nmore.", b"." * 40 + b" a"]
+    text, off = corpus.concat_docs(docs)
+    om = oracle_models(model)
+    for chunk in (0, 64, None):
+        res, tot = run_batch(gpu(model), text, off, chunk=chunk)
+        assert_batch_equals_oracle(om, res, text, off)
+    exp = om.transduce_doc(docs[6], 0)  # 40 full stops
+    assert list(zip(exp.tok_bstart.tolist(), exp.tok_bend.tolist())) == [(0, 40), (41, 41)]
+    assert list(zip(exp.tok_rstart.tolist(), exp.tok_rend.tolist())) == [(0, 40), (41, 41)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["tokenizer_de.matok", "tokenizer_en.matok", "tokenizer_de.datok"])
+def test_token_offset_behind_its_buffer_is_reported(gpu, oracle_models, model):
+    """"x ....\\n\\n" at the end of a document: after the hard fail the epsilon slot lies behind the token start, and
+    the reference calls Token(offset, buf) with offset > len(buf) -- string(buf[offset:]) panics where surfaces are
+    printed (token_writer.go:85,93).  Reported as DTK_ST_BAD_OFFSET by the GPU path and by the oracle alike;
+    neighbouring documents are untouched."""
+    import datok_amd
+    from datok_amd import corpus
+    docs = [b"Vorher. ", b"x ....\n\n", b"a ....." + b"\n" * 400 + b" ", b"x ... \n", b"Nachher ...\n"]
+    text, off = corpus.concat_docs(docs)
+    om = oracle_models(model)
+    for chunk in (0, 64, None):
+        res, tot = run_batch(gpu(model), text, off, chunk=chunk)
+        assert_batch_equals_oracle(om, res, text, off)
+        st = [int(res.status[d]) for d in range(len(docs))]
+        assert st[1] & datok_amd.ST_BAD_OFFSET and st[2] & datok_amd.ST_BAD_OFFSET
+        assert st[0] == 0 and st[3] == 0 and st[4] == 0
