@@ -73,6 +73,10 @@ def long_docs(rng, n):
     for _ in range(n):
         text, off = random_docs(rng, int(rng.integers(40, 200)))
         raw = bytearray(text.tobytes())
+        if rng.integers(0, 3) == 0:   # blank-free tokens longer than chunks inside a long document
+            g, _ = long_token_docs(rng, int(rng.integers(2, 8)))
+            cut = int(rng.integers(0, len(raw) + 1))
+            raw[cut:cut] = g.tobytes() + b" "
         if rng.integers(0, 2):
             g, _ = corpus.german_docs(int(rng.integers(4, 24)), 4096, seed=int(rng.integers(0, 1 << 30)))
             cut = int(rng.integers(0, len(raw) + 1))
