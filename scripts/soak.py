@@ -86,7 +86,8 @@ def long_docs(rng, n):
 
 
 models = {name: (datok_amd.load_tokenizer_file(os.path.join(M, name)), O.Model(os.path.join(M, name)))
-          for name in ("tokenizer_de.matok", "tokenizer_en.matok", "tokenizer_de.datok", "clitic_test.matok")}
+          for name in ("tokenizer_de.matok", "tokenizer_en.matok", "tokenizer_de.datok", "clitic_test.matok",
+                       "simpletok.matok", "simpletok.datok", "bauamt.fst", "wahlamt.fst", "ignorable_mcs.fst")}
 t0 = time.time()
 total_docs = 0
 for seed in range(first, first + n_seeds):
