@@ -8,6 +8,7 @@
 #define DTK_RESTBIT 0x3fffffffu    // datok.go:45
 #define DTK_EOT 4u                 // matrix.go:13
 #define DTK_WINDOW 1024u           // matrix.go:365
+#define DTK_WINDOW_BYTES 4104u     // more bytes than 1024 runes can have: the window has overflowed for certain
 
 // ---- symbol stream entry (uint16 per input byte), written by the symbolise kernel
 //   [10:0]  sigma index a           (sigmaASCII[c] / sigma[c] / identity, matrix.go:421-435)

@@ -685,7 +685,8 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
     // longest), end of this lane's chunk
     // a fused cell rewinds before its rune: that rewind is at p_old, never the end of the chunk
     const bool rewind_end = (flush && !comp) || (IS_MATRIX && eot_now);
-    if (eot_now || (rewind && hi - bs > DTK_WINDOW) || (rewind_end && MODE != MODE_DOC && p >= stop_pos)) {
+    const bool long_win = hi - bs > DTK_WINDOW_BYTES;  // overflowed for certain: the lane stops (see walk_fused)
+    if (eot_now || (rewind && hi - bs > DTK_WINDOW) || (rewind_end && MODE != MODE_DOC && p >= stop_pos) || long_win) {
       if (eot_now) {
         if (MODE != MODE_START) sink.template eot<IS_MATRIX>(p, eot_sent, has_tok);
         has_tok = false;  // TextEnd: pos = pos[:0] (token_writer.go:158)
@@ -700,6 +701,8 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
           done = true;
         }
       }
+      // (the tail below then closes the document at this position: every document keeps its TextEnd)
+      if (long_win && !done) { st |= ST_WINDOW_OVERFLOW; done = true; }
     }
     tp = rewind_end ? p : tp;  // matrix.go:537-543 / 608-627
     bs = rewind_end ? p : (flush_c ? p_old : bs);
@@ -836,7 +839,11 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
     const bool eot_now = (advance || comp) && ((e >> DTK_SYM_CLS_SHIFT) & 3u) == 1u;  // matrix.go:593-605
     const bool over = flush && hi - bs_old > DTK_WINDOW;
     const bool at_stop = rewE && MODE != MODE_DOC && p >= stop_pos;
-    if (hardfail || eot_now || over || at_stop || it > cap) {
+    // more bytes buffered than 1024 runes can have: the reference's window has overflowed for certain
+    // (matrix.go:365,406).  The lane stops there -- a blank-free blob of megabytes would otherwise
+    // be walked to its end by every lane whose chunk lies inside it.
+    const bool long_win = hi - bs > DTK_WINDOW_BYTES;
+    if (hardfail || eot_now || over || at_stop || it > cap || long_win) {
       if (hardfail) {  // matrix.go:499-552: drop what is buffered as a token, restart at state 1
         if (r) { st |= ST_BAD_MODEL; done = true; }
         else {
@@ -873,6 +880,8 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
         done = true;
       }
       if (it > cap && !done) { st |= ST_STEP_LIMIT; done = true; }
+      // (the tail below then closes the document at this position: every document keeps its TextEnd)
+      if (long_win && !done) { st |= ST_WINDOW_OVERFLOW; done = true; }
     }
     if (!done) { DTK_EOF_DRAIN() }
     // one list of the wave is nearly full: all lanes write theirs out

@@ -130,7 +130,13 @@ for seed in range(first, first + n_seeds):
             for d in keep[::max(1, len(keep) // 40)]:
                 exp, est = om.transduce(raw[int(off[d]):int(off[d + 1])], 3 | flags)
                 if est == 0 and not (int(res.status[d]) & ~datok_amd.ST_EMPTY_TEXT):
-                    assert data[int(o[d]):int(o[d + 1])] == exp, (seed, name, d)
+                    if data[int(o[d]):int(o[d + 1])] != exp:
+                        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                        np.savez(os.path.join(ROOT, "gpurun_out", "soak_fail.npz"), text=text, off=off, model=name, flags=flags,
+                                 chunk=-1 if chunk is None else chunk, warm=warm, extend=-1 if extend is None else extend,
+                                 seed=seed, doc=d, got=np.frombuffer(data[int(o[d]):int(o[d + 1])], dtype=np.uint8),
+                                 exp=np.frombuffer(exp, dtype=np.uint8))
+                        raise AssertionError(("rendered text differs", seed, name, d))
             total_docs += len(keep)
     if (seed - first) % 5 == 4:
         print("seed %d ok: %d documents checked, %.0f s" % (seed, total_docs, time.time() - t0), flush=True)

@@ -23,6 +23,12 @@ def assert_batch_equals_oracle(omodel, res, text: np.ndarray, doc_off: np.ndarra
         a, b = int(doc_off[d]), int(doc_off[d + 1])
         exp = oracle_doc(omodel, raw[a:b], flags)
         got = res.doc(d)
+        if exp["status"] & 1:
+            # WINDOW_OVERFLOW: the reference dies at the first overflow (matrix.go:365,406 index panic); the GPU path
+            # stops a walk whose window has overflowed for certain (more bytes than 1024 runes can have) and closes
+            # the document there, the oracle runs on -- what either of them flags behind that point means nothing
+            assert got["status"] & 1, (d, got["status"], exp["status"], raw[a:b][:80])
+            continue
         assert (got["status"] & ~allow_status) == (exp["status"] & ~allow_status), (d, got["status"], exp["status"], raw[a:b][:80])
         if exp["status"]:
             continue

@@ -651,3 +651,30 @@ def test_token_offset_behind_its_buffer_is_reported(gpu, oracle_models, model):
         st = [int(res.status[d]) for d in range(len(docs))]
         assert st[1] & datok_amd.ST_BAD_OFFSET and st[2] & datok_amd.ST_BAD_OFFSET
         assert st[0] == 0 and st[3] == 0 and st[4] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["tokenizer_de.matok", "tokenizer_de.datok"])
+def test_blank_free_blob_is_flagged_quickly(gpu, oracle_models, model):
+    """A blank-free blob of 2 MB inside a document (minified code, base64): the reference's 1024-rune window
+    overflows, the document is out of contract.  Every lane whose window holds more bytes than 1024 runes can have
+    stops, so the blob is not walked to its end by each of the 16 000 lanes whose chunk lies inside it (quadratic);
+    the document comes back flagged and closed, its neighbours exact, in well under a second."""
+    import time
+    import datok_amd
+    from datok_amd import corpus
+    rng = np.random.default_rng(3)
+    blob = bytes(rng.choice(np.frombuffer(b"abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789+/", dtype=np.uint8),
+                            size=2 << 20))
+    docs = [b"Davor ein Satz. Und noch einer.", b"Anfang " + blob + b" Ende. Danach.", b"Danach ein Dokument."]
+    text, off = corpus.concat_docs(docs)
+    with datok_amd.Batch(len(text), len(off) - 1) as b:
+        b.set_input(text, off)
+        b.run(gpu(model), 0); b.totals()          # first run: allocations
+        t0 = time.perf_counter()
+        b.run(gpu(model), 0); tot = b.totals(); res = b.result()
+        dt = time.perf_counter() - t0
+    st = [int(x) for x in res.status]
+    assert st[1] & datok_amd.ST_WINDOW_OVERFLOW and st[0] == 0 and st[2] == 0, st
+    assert_batch_equals_oracle(oracle_models(model), res, text, off)
+    assert dt < 0.5, dt
