@@ -676,5 +676,5 @@ def test_blank_free_blob_is_flagged_quickly(gpu, oracle_models, model):
         dt = time.perf_counter() - t0
     st = [int(x) for x in res.status]
     assert st[1] & datok_amd.ST_WINDOW_OVERFLOW and st[0] == 0 and st[2] == 0, st
-    assert_batch_equals_oracle(oracle_models(model), res, text, off)
+    assert_batch_equals_oracle(oracle_models(model), res, text, off, docs=[0, 2])  # (the oracle is quadratic on the blob)
     assert dt < 0.5, dt
