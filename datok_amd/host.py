@@ -307,7 +307,7 @@ class Batch:
 
     AUTO_CHUNK = 0xFFFFFFFF
 
-    def set_chunking(self, chunk_bytes=AUTO_CHUNK, warm_bytes=48, extend=None):
+    def set_chunking(self, chunk_bytes=AUTO_CHUNK, warm_bytes=16, extend=None):
         """0: one lane per document; otherwise speculative chunk lanes (exact either way).
         extend: how far the warm-up start may move back to the previous blank (None: library default,
         0: fixed distance only -- what tests use to force mispredictions)."""

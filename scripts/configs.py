@@ -26,7 +26,7 @@ def run(name, model, text, off, in_flight=3, steps=30):
     for _ in range(in_flight):
         b = datok_amd.Batch(max(len(text), 1), n_docs)
         if os.environ.get("CHUNK"):
-            b.set_chunking(int(os.environ["CHUNK"]), 48)
+            b.set_chunking(int(os.environ["CHUNK"]))
         b.set_input(text, off)
         bs.append(b)
     bs[0].run(tok, 0)
