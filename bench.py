@@ -3,16 +3,21 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A step is one pass of the hot path (symbolise -> walk -> compact, i.e. one
-data-parallel TransduceTokenWriter) over one batch of synthetic German
-documents that is already resident in HBM.  N = 1 runs BASELINE.json
-configs[1] (4096 equal-length 4 KiB documents); N > 1 is launched by
-torch.distributed.run, one rank per GPU, each rank walking its own shard of
-the same shape (weak scaling, no data-path collective: documents are
-independent).  After the timed region the per-shard offset arrays are gathered
-to rank 0 over RCCL once, outside the clock, and reported as gather_ms.
+A step is one pass of the hot path (symbolise -> walk -> compact, i.e. one data-parallel
+TransduceTokenWriter) over one batch of synthetic German documents that is already resident in HBM,
+INCLUDING the host-side completion of that batch (dtk_batch_totals: the speculation check, the repair
+rounds if any, the output-capacity check, the totals) before its buffers are used again.
 
-Rank 0 prints one JSON line.  `value` is whole-job MB/s (1e6 bytes/s).
+N = 1 runs BASELINE.json configs[1] (4096 equal-length 4 KiB documents per batch; a few batches in
+flight, each with its own input, HIP stream and buffers).  N > 1 is launched by torch.distributed.run,
+one rank per GPU, and runs configs[4] as each GPU sees it: the 10 GiB corpus = 2 621 440 documents of
+4 KiB sharded 8 ways = 327 680 documents (1.25 GiB) per rank, seed 5000 + rank, one batch (weak scaling,
+no data-path collective: documents are independent).  After the timed region the per-shard offset
+arrays (tok_rstart, tok_rend, sent) are gathered to rank 0 over RCCL once, outside the clock
+(gather_ms).
+
+Rank 0 prints one JSON line.  `value` is whole-job MB/s (1e6 bytes/s) with inputs resident in HBM;
+`end_to_end` is the same work fed from pinned host memory through dtk_batch_set_input (PCIe inclusive).
 """
 import argparse
 import json
@@ -30,21 +35,22 @@ MODEL = os.path.join(ROOT, "tests", "golden", "models", "tokenizer_de.matok")
 # renderer of the writer's text output needs is not requested (datok_gpu.h: DTK_OFFSETS_ONLY)
 RUN_FLAGS = 256
 HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md: 8 TB/s, 6.29 TB/s measured copy)
+SHARD_DOCS = 327680  # configs[4]: 10 GiB / 4 KiB / 8 GPUs
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--docs", type=int, default=4096, help="documents per GPU")
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--docs", type=int, default=0, help="documents per batch (default: 4096 at N = 1, 327680 at N > 1)")
     ap.add_argument("--doc-bytes", type=int, default=4096)
     ap.add_argument("--model", default=MODEL)
     ap.add_argument("--chunk", type=int, default=-1, help="-1 automatic, 0 one lane per document, else bytes")
     ap.add_argument("--warm", type=int, default=16)
-    ap.add_argument("--streams", type=int, default=3,
-                    help="batches in flight: consecutive steps alternate between this many dtk_batch objects "
-                         "(each with its own HIP stream and buffers) over the same resident input")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="batches in flight (default 3 at N = 1, 1 at N > 1): consecutive steps alternate between "
+                         "this many dtk_batch objects, each with its own input (seeds 2, 3, ...), HIP stream and buffers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--parity-docs", type=int, default=256, help="documents checked against the oracle before timing")
@@ -64,11 +70,51 @@ def walk_kernel_name(total_bytes):
     return base + "<%s, true, " + ("true" if lists else "false") + ">"
 
 
+def timed_steps(batches, tok, steps, barrier):
+    """K steps, round-robin over the batches.  A batch is completed on the host (totals(): speculation check,
+    repairs, capacity check) before it is run again and at the end -- all of it inside the clock."""
+    barrier()
+    t0 = time.perf_counter()
+    ran = [False] * len(batches)
+    for i in range(steps):
+        k = i % len(batches)
+        if ran[k]:
+            batches[k].totals()
+        batches[k].run(tok, RUN_FLAGS)
+        ran[k] = True
+    for k, bb in enumerate(batches):
+        if ran[k]:
+            bb.totals()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    return elapsed
+
+
+def stage_times(batches, tok, steps):
+    """Average milliseconds per stage (HIP events on each batch's own stream, recorded around the kernels of
+    dtk_batch_run), in the same regime as the timed region: same batches in flight, same completion calls."""
+    for bb in batches:
+        bb.set_profiling(True)
+    acc, n = {}, 0
+    for rep in range(4):
+        ran = [False] * len(batches)
+        for i in range(max(steps // 4, 2 * len(batches))):
+            k = i % len(batches)
+            if ran[k]:
+                batches[k].totals()
+            batches[k].run(tok, RUN_FLAGS)
+            ran[k] = True
+        for bb in batches:
+            for name, v in bb.stage_ms().items():
+                acc[name] = acc.get(name, 0.0) + v
+            n += 1
+    for bb in batches:
+        bb.set_profiling(False)
+    return {k: v / n for k, v in acc.items()}
+
+
 def main():
     args = parse()
-    import torch
-    import torch.distributed as dist
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -77,6 +123,23 @@ def main():
             sys.exit("bench.py: --gpus %d needs `python -m torch.distributed.run --nproc-per-node %d ...`"
                      % (args.gpus, args.gpus))
         args.gpus = world
+    n_docs = args.docs or (4096 if world == 1 else SHARD_DOCS)
+    n_streams = args.streams or (3 if world == 1 else 1)
+
+    # ---- inputs first (the sharded generator uses worker processes: before anything touches the GPU)
+    from datok_amd import corpus
+    inputs, seeds = [], []
+    for k in range(n_streams):
+        if world == 1 and n_docs <= 65536:
+            seeds.append(2 + k)
+            inputs.append(corpus.german_docs(n_docs, args.doc_bytes, seed=seeds[-1]))
+        else:
+            seeds.append(5000 + rank + 100 * k)
+            inputs.append(corpus.german_docs_sharded(n_docs, args.doc_bytes, seed=seeds[-1]))
+    total = int(inputs[0][1][-1])
+
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible (the hot path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -86,47 +149,51 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)
 
     import datok_amd
-    from datok_amd import corpus
-
     datok_amd.lib().dtk_set_device(local_rank)
     tok = datok_amd.load_tokenizer_file(args.model)
     if tok is None:
         sys.exit("bench.py: cannot load " + args.model)
 
-    # ---- this rank's shard: same generator, rank-dependent seed
-    seed = 2 if world == 1 else 5 * 1000 + rank
-    text, doc_off = corpus.german_docs(args.docs, args.doc_bytes, seed=seed)
-    total = int(doc_off[-1])
-    t_text = torch.from_numpy(text).to(dev)
-    t_off = torch.from_numpy(doc_off.view(np.int64)).to(dev)
+    # ---- resident inputs: one per batch in flight
+    resident, batches = [], []
+    for text, doc_off in inputs:
+        t_text = torch.from_numpy(text).to(dev)
+        t_off = torch.from_numpy(doc_off.view(np.int64)).to(dev)
+        resident.append((t_text, t_off))
     torch.cuda.synchronize()
-
-    batches = []
-    for _ in range(max(1, args.streams)):
-        bb = datok_amd.Batch(total, args.docs)
+    for (text, doc_off), (t_text, t_off) in zip(inputs, resident):
+        bb = datok_amd.Batch(total, n_docs)
         bb.set_chunking(datok_amd.Batch.AUTO_CHUNK if args.chunk < 0 else args.chunk, args.warm)
-        bb.set_input_device(t_text.data_ptr(), t_off.data_ptr(), args.docs, total,
-                            keep=(t_text, t_off), doc_off_host=doc_off)
+        bb.set_input_device(t_text.data_ptr(), t_off.data_ptr(), n_docs, total, keep=(t_text, t_off), doc_off_host=doc_off)
         batches.append(bb)
     batch = batches[0]
+    text, doc_off = inputs[0]
 
-    # ---- parity gate (oracle is the checker, never the thing measured)
-    batch.run(tok, RUN_FLAGS)
-    tot = batch.totals()
-    if rank == 0 and args.parity_docs:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from parity import assert_batch_equals_oracle
-        from oracle import oracle as O
-        om = O.Model(args.model)
-        res = batch.result()
-        step = max(1, args.docs // args.parity_docs)
-        n = assert_batch_equals_oracle(om, res, text, doc_off, docs=range(0, args.docs, step))
-        assert tot["n_flagged"] == 0 and n > 0
-        del res
+    # ---- parity gate (oracle is the checker, never the thing measured): every batch in flight, sampled documents
+    tot = None
+    for k, bb in enumerate(batches):
+        bb.run(tok, RUN_FLAGS)
+        tk = bb.totals()
+        tot = tot or tk
+        if args.parity_docs:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from parity import assert_batch_equals_oracle
+            from oracle import oracle as O
+            om = O.Model(args.model)
+            res = bb.result()
+            step = max(1, n_docs // max(1, args.parity_docs // len(batches)))
+            n = assert_batch_equals_oracle(om, res, inputs[k][0], inputs[k][1], docs=range(0, n_docs, step))
+            assert tk["n_flagged"] == 0 and n > 0
+            del res
 
     # ---- warmup
+    ran = [False] * len(batches)
     for i in range(args.warmup):
-        batches[i % len(batches)].run(tok, RUN_FLAGS)
+        k = i % len(batches)
+        if ran[k]:
+            batches[k].totals()
+        batches[k].run(tok, RUN_FLAGS)
+        ran[k] = True
     for bb in batches:
         bb.sync()
 
@@ -136,41 +203,62 @@ def main():
         torch.cuda.synchronize()
 
     # ---- timed region: exactly K steps
-    batch.set_profiling(False)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        batches[i % len(batches)].run(tok, RUN_FLAGS)
-    for bb in batches:
-        bb.sync()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    barrier()
+    elapsed = timed_steps(batches, tok, args.steps, barrier)
     if world > 1:
         te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
+    repair_rounds = max(int(bb.totals()["repair_rounds"]) for bb in batches)
 
-    # ---- per-kernel time of the dominant kernel (the walk): HIP events on each batch's own
-    #      stream, in the same regime as the timed region (same number of batches in flight,
-    #      no host synchronisation between steps); the events of the last run of every batch
-    #      are read after the region, and the region is repeated a few times
-    for bb in batches:
-        bb.set_profiling(True)
-    stage_sum, n_samples = {}, 0
-    for rep in range(4):
-        for i in range(max(args.steps // 4, 2 * len(batches))):
-            batches[i % len(batches)].run(tok, RUN_FLAGS)
-        for bb in batches:
-            for k, v in bb.stage_ms().items():
-                stage_sum[k] = stage_sum.get(k, 0.0) + v
-            n_samples += 1
-    stage_avg = {k: v / n_samples for k, v in stage_sum.items()}
-    for bb in batches:
-        bb.set_profiling(False)
+    # ---- per-kernel times: the regime of the timed region, and one batch alone on the GPU
+    stage_avg = stage_times(batches, tok, args.steps)
+    one = None
+    if len(batches) > 1:
+        e1 = timed_steps(batches[:1], tok, args.steps, barrier)
+        s1 = stage_times(batches[:1], tok, args.steps)
+        one = {"value": round(total * args.steps / e1 / 1e6, 1), "ms_per_step": round(e1 / args.steps * 1e3, 4),
+               "kernel_ms": round(s1["walk"], 4), "stages_ms": {k: round(v, 4) for k, v in s1.items()}}
+
+    # ---- PCIe inclusive: the same batches fed from pinned host memory (set_input: H2D on the batch's stream,
+    #      then the run on the same stream; with several batches the upload of one overlaps the kernels of the others)
+    h2d = None
+    if rank == 0:
+        pinned = [(torch.from_numpy(t).pin_memory(), o) for t, o in inputs]
+        hb = []
+        for (pt, o) in pinned:
+            bb = datok_amd.Batch(total, n_docs)
+            bb.set_chunking(datok_amd.Batch.AUTO_CHUNK if args.chunk < 0 else args.chunk, args.warm)
+            hb.append(bb)
+        for bb, (pt, o) in zip(hb, pinned):
+            bb.set_input(pt.numpy(), o); bb.run(tok, RUN_FLAGS); bb.totals()
+        t0 = time.perf_counter()
+        for i in range(8):
+            bb, (pt, o) = hb[i % len(hb)], pinned[i % len(hb)]
+            bb.set_input(pt.numpy(), o)
+            bb.sync()
+        h2d_ms = (time.perf_counter() - t0) / 8 * 1e3
+        ksteps = max(len(hb) * 4, min(args.steps, 24))
+        t0 = time.perf_counter()
+        ran = [False] * len(hb)
+        for i in range(ksteps):
+            k = i % len(hb)
+            if ran[k]:
+                hb[k].totals()
+            hb[k].set_input(pinned[k][0].numpy(), pinned[k][1])
+            hb[k].run(tok, RUN_FLAGS)
+            ran[k] = True
+        for bb in hb:
+            bb.totals()
+        e2e = time.perf_counter() - t0
+        h2d = {"h2d_ms": round(h2d_ms, 4), "h2d_GBps": round(total / h2d_ms / 1e6, 2),
+               "end_to_end_MBps": round(total * ksteps / e2e / 1e6, 1), "steps": ksteps,
+               "what": "pinned host text + offsets -> dtk_batch_set_input -> run -> totals, %d batches in flight" % len(hb)}
+        for bb in hb:
+            bb.close()
+        del pinned
 
     # ---- offset gather to rank 0 over RCCL (config 5's exchange), outside the clock
-    gather_ms, gather_hung = None, False
+    gather_ms, gather_hung, gather_err = None, False, None
     if world > 1:
         from datok_amd import shard
         v = batch.result_device()
@@ -203,19 +291,22 @@ def main():
                 box["ms"] = (time.perf_counter() - g0) * 1e3
                 if rank == 0:
                     assert sum(int(t.numel()) for t in got["tok_rstart"]) >= ntok
+                    box["bytes"] = sum(int(t.numel()) * 4 for ts in got.values() for t in ts)
             except Exception as e:  # report, do not lose the run
                 box["err"] = repr(e)
         th = threading.Thread(target=_gather, daemon=True)
         th.start()
-        th.join(timeout=float(os.environ.get("DATOK_GATHER_TIMEOUT", "90")))
+        th.join(timeout=float(os.environ.get("DATOK_GATHER_TIMEOUT", "120")))
         gather_hung = th.is_alive()
-        if gather_hung or "err" in box:
-            print("bench.py: offset gather %s on rank %d" % ("timed out" if gather_hung else "failed: " + box["err"], rank),
+        gather_err = box.get("err")
+        if gather_hung or gather_err:
+            print("bench.py: offset gather %s on rank %d" % ("timed out" if gather_hung else "failed: " + gather_err, rank),
                   file=sys.stderr)
         gather_ms = box.get("ms")
+        gather_bytes = box.get("bytes")
         # no barrier behind the gather: a rank whose peer is stuck must still get to its output
 
-    # ---- CPU baseline: the C restatement of the Go algorithm, rank 0, N = 1 only
+    # ---- CPU baseline: the C restatement of the Go algorithm, rank 0, N = 1 only, on the first batch's input
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
@@ -224,7 +315,7 @@ def main():
         om.count_batch(text[: 64 * args.doc_bytes], doc_off[:65], 1)
         t1 = time.perf_counter()
         om.count_batch(text, doc_off, 1)
-        one = total / (time.perf_counter() - t1) / 1e6
+        one_thread = total / (time.perf_counter() - t1) / 1e6
         reps, spent = 0, 0.0
         t1 = time.perf_counter()
         while spent < args.cpu_seconds:
@@ -232,16 +323,16 @@ def main():
             reps += 1
             spent = time.perf_counter() - t1
         cpu = {"value": round(reps * total / spent / 1e6, 1), "unit": "MB/s", "cores": cores, "kind": "port",
-               "sample": "the same %d x %d B batch, %d passes, %d threads (oracle/datok_oracle.c, C restatement "
-                         "of matrix.go:348-698, counting sink)" % (args.docs, args.doc_bytes, reps, cores),
-               "single_thread_MBps": round(one, 1),
+               "sample": "the first %d x %d B batch, %d passes, %d threads (oracle/datok_oracle.c, C restatement "
+                         "of matrix.go:348-698, counting sink)" % (n_docs, args.doc_bytes, reps, cores),
+               "single_thread_MBps": round(one_thread, 1),
                "reference_published_MBps_per_core": 24.8}
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         value = world * total * args.steps / elapsed / 1e6
         # algorithmic bytes of one launch: input + doc offsets + i32 offsets out + counts
-        b_alg = total + 4 * (args.docs + 1) + 4 * (2 * tot["n_tokens"] + tot["n_sent"]) + 8 * args.docs
+        b_alg = total + 4 * (n_docs + 1) + 4 * (2 * tot["n_tokens"] + tot["n_sent"]) + 8 * n_docs
         walk_s = stage_avg["walk"] * 1e-3
         achieved = b_alg / walk_s / 1e9
         split = os.environ.get("DATOK_SPLIT_START", "0") not in ("", "0")
@@ -250,21 +341,25 @@ def main():
         traffic = None
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            if tr.get("docs") == args.docs and tr.get("doc_bytes") == args.doc_bytes and \
+            if tr.get("docs") == n_docs and tr.get("doc_bytes") == args.doc_bytes and \
                     tr.get("chunk_bytes") == tot["chunk_bytes"]:
                 traffic = tr["walk_kernel_hbm_bytes"]
         except (OSError, ValueError, KeyError):
             pass
+        workload = ("tokenizer_de.matok, %d equal-length %d B synthetic German docs per batch (BASELINE.json configs[1])"
+                    if world == 1 else
+                    "tokenizer_de.matok, one shard of the 10 GiB corpus per GPU: %d docs x %d B (BASELINE.json configs[4])")
         out = {
             "metric": "input MB/s tokenized, tokenizer_de.matok",
             "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
-            "config": {"workload": "tokenizer_de.matok, %d equal-length %d B synthetic German docs per GPU "
-                                   "(BASELINE.json configs[1])" % (args.docs, args.doc_bytes),
-                       "docs_per_gpu": args.docs, "doc_bytes": args.doc_bytes,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u32 table cells, u16 symbols", "data": "synthetic",
+            "config": {"workload": workload % (n_docs, args.doc_bytes),
+                       "docs_per_gpu": n_docs, "doc_bytes": args.doc_bytes,
                        "parallelism": "documents sharded over %d GPU(s), no data-path collective" % world,
-                       "batches_in_flight": len(batches)},
+                       "batches_in_flight": len(batches),
+                       "inputs": "one per batch in flight (generator seeds %s on rank 0)" % ", ".join(map(str, seeds)),
+                       "step": "dtk_batch_run + dtk_batch_totals (speculation check, repairs, capacity check) per batch"},
             "roofline": {"bound": "hbm",
                          "kernel": (walk_kernel_name(total) if tot["chunk_bytes"] else "k_walk_doc<%s, true>") % (
                              ("MatrixLeanTrans" if not tok.info["unknown_used"] else "MatrixFusedTrans")
@@ -274,20 +369,27 @@ def main():
                          "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 6),
                          "traffic": traffic, "algorithmic_bytes": int(b_alg),
                          "kernel_ms": round(stage_avg["walk"], 4),
+                         "kernel_ms_note": "average launch duration with %d batches in flight (kernels of different "
+                                           "batches share the CUs); one batch alone: streams_1.kernel_ms" % len(batches),
                          "lookups_per_launch": int(tot["walk_steps"]),
                          "Glookups_per_s_start_plus_walk": round(tot["walk_steps"] / both_s / 1e9, 3)},
             "stages_ms": {k: round(v, 4) for k, v in stage_avg.items()},
+            "streams_1": one,
+            "end_to_end": h2d,
             "tokens_per_launch": int(tot["n_tokens"]),
             "walk": {"lanes": int(tot["n_lanes"]), "chunk_bytes": int(tot["chunk_bytes"]), "warm_bytes": args.warm,
-                     "repair_rounds": int(tot["repair_rounds"])},
+                     "repair_rounds": repair_rounds},
             "gather_ms": None if gather_ms is None else round(gather_ms, 3),
+            "gather_hung": bool(gather_hung), "gather_error": gather_err,
             "cpu_baseline": cpu,
         }
+        if world > 1 and gather_ms is not None:
+            out["gather_GBps"] = round(gather_bytes / gather_ms / 1e6, 2)
         print(json.dumps(out))
     if world > 1:
-        if gather_hung:
+        if gather_hung or gather_err:
             sys.stdout.flush()
-            os._exit(0)  # a stuck point-to-point operation would also block the teardown
+            os._exit(3)  # a stuck point-to-point operation would also block the teardown
         dist.destroy_process_group()
 
 

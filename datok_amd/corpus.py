@@ -183,6 +183,30 @@ def german_docs(n_docs=4096, doc_bytes=4096, seed=2, n_sent=20000):
     return _fixed_docs(rng, pool, n_docs, doc_bytes, [b" ", b" ", b" ", b" ", b" ", b" ", b" ", b"\n\n", b"\n"])
 
 
+def _german_part(args):
+    n_docs, doc_bytes, seed = args
+    return german_docs(n_docs, doc_bytes, seed)[0]
+
+
+def german_docs_sharded(n_docs, doc_bytes=4096, seed=5, parts=16, workers=None):
+    """Config 5 (one shard of the 10 GiB corpus is 327 680 x 4 KiB): the same generator run as `parts` independent
+    sub-streams (seeds seed * 1000 + part) in a process pool -- the single-threaded generator makes about 10 MB/s.
+    The bytes depend on (n_docs, doc_bytes, seed, parts) only, not on the number of workers."""
+    import multiprocessing as mp
+    import os
+    per = [n_docs // parts + (1 if i < n_docs % parts else 0) for i in range(parts)]
+    jobs = [(per[i], doc_bytes, seed * 1000 + i) for i in range(parts) if per[i]]
+    workers = workers or min(len(jobs), os.cpu_count() or 1)
+    if workers <= 1:
+        chunks = [_german_part(j) for j in jobs]
+    else:
+        with mp.get_context("spawn").Pool(workers) as pool:   # spawn: the parent may hold a GPU context
+            chunks = pool.map(_german_part, jobs)
+    text = np.concatenate(chunks)
+    doc_off = np.arange(n_docs + 1, dtype=np.uint64) * np.uint64(doc_bytes)
+    return text, doc_off
+
+
 def english_zipf_docs(n_docs=65536, seed=3, min_bytes=64, max_bytes=65536, n_sent=20000):
     """Config 3: lengths 64*2^k clipped to [64 B, 64 KiB], P(k) ~ 1/(k+1)."""
     rng = np.random.default_rng(seed)

@@ -744,6 +744,15 @@ struct dtk_batch {
   uint32_t render_flags = 0xFFFFFFFFu;  // flags of the rendering held in d_out (none)
   std::vector<uint8_t> h_out;
   std::vector<uint64_t> h_out_off;
+  // the exact pass over ST_IRREGULAR documents (normally none): ids, call counts / offsets, calls
+  uint32_t *d_exact_ids = nullptr, *d_exact_cnt = nullptr;
+  uint64_t *d_exact_off = nullptr;
+  DtkCall *d_calls = nullptr;
+  uint32_t exact_cap = 0;
+  uint64_t calls_cap = 0;
+  std::vector<uint32_t> h_exact_ids;
+  std::vector<uint64_t> h_exact_off;
+  std::vector<DtkCall> h_calls;
   // optional stage timing
   bool profiling = false;
   hipEvent_t ev[DTK_N_STAGES + 1] = {};
@@ -823,7 +832,7 @@ extern "C" int dtk_batch_create(uint64_t max_bytes, uint32_t max_docs, dtk_batch
   B_TRY(hipMalloc((void **)&b->d_scan_ws, ((uint64_t)max_docs / 2048 + 2) * 4 * 8));
   B_TRY(hipMalloc((void **)&b->d_out_off, ((uint64_t)max_docs + 1) * 8));
 
-  B_TRY(hipHostMalloc((void **)&b->h_totals, 8 * 8, hipHostMallocDefault));
+  B_TRY(hipHostMalloc((void **)&b->h_totals, 16 * 8, hipHostMallocDefault));  // [0..7] device totals, [8] render size
 #undef B_TRY
   // typical German: 0.18 tokens and 0.06 sentence ints per byte; grown on demand
   int rc = alloc_outputs(b, max_bytes / 3 + max_docs + 16, max_bytes / 8 + 2ull * max_docs + 16,
@@ -842,7 +851,8 @@ extern "C" void dtk_batch_free(dtk_batch *b) {
                   b->d_tok_off,
                   b->d_sent_off, b->d_text_off, b->d_rstart, b->d_rend, b->d_sent,
                   b->d_bstart, b->d_bend, b->d_ttok, b->d_tsent,
-                  b->d_sbefore, b->d_ts_end, b->d_doc_ns, b->d_scan_ws, b->d_rws, b->d_out_off, b->d_out};
+                  b->d_sbefore, b->d_ts_end, b->d_doc_ns, b->d_scan_ws, b->d_rws, b->d_out_off, b->d_out,
+                  b->d_exact_ids, b->d_exact_cnt, b->d_exact_off, b->d_calls};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (b->h_totals) (void)hipHostFree(b->h_totals);
@@ -868,13 +878,19 @@ extern "C" int dtk_batch_set_input(dtk_batch *b, const uint8_t *text, const uint
   HIP_TRY(hipStreamSynchronize(b->stream));  // previous run may still read the buffers
   if (total) HIP_TRY(hipMemcpyAsync(b->d_text_own, text, total, hipMemcpyHostToDevice, b->stream));
   HIP_TRY(hipMemcpyAsync(b->d_off_own, doc_off, ((uint64_t)n_docs + 1) * 8, hipMemcpyHostToDevice, b->stream));
+  // the lane plan only depends on the offsets: a stream of equally shaped batches keeps it
+  const bool same = b->plan_valid && b->d_off == b->d_off_own && b->n_docs == n_docs &&
+                    b->h_doc_off.size() == (size_t)n_docs + 1 &&
+                    memcmp(b->h_doc_off.data(), doc_off, ((size_t)n_docs + 1) * 8) == 0;
   b->d_text = b->d_text_own;
   b->d_off = b->d_off_own;
   b->n_docs = n_docs;
   b->total = total;
   b->ran = false;
-  b->h_doc_off.assign(doc_off, doc_off + n_docs + 1);
-  b->plan_valid = false;
+  if (!same) {
+    b->h_doc_off.assign(doc_off, doc_off + n_docs + 1);
+    b->plan_valid = false;
+  }
   return DTK_OK;
 }
 
@@ -1069,6 +1085,7 @@ static int launch_compact2(dtk_batch *b) {
   a.n_segs = b->n_segs; a.chunk_off = b->d_chunk_off; a.lane_start = b->d_lane_start; a.lane_cnt = b->d_lane_cnt;
   a.seg_sum = b->d_seg_sum; a.seg_in = b->d_seg_in;
   a.doc_seq = b->d_seg_tab + 3 * (size_t)b->seg_cap + b->max_docs + 1;
+  a.any_irregular = (uint32_t *)(b->d_totals + 7);
   b->last_args = a;
   if (seg && dtk_launch_seg_prepare(&a, b->d_seg_tab + 3 * (size_t)b->seg_cap, b->stream))
     return hip_fail(hipGetLastError(), "segment carries");
@@ -1193,6 +1210,70 @@ extern "C" int dtk_batch_sync(dtk_batch *b) {
   return DTK_OK;
 }
 
+// The exact pass (k_exact_doc): documents flagged ST_IRREGULAR by the walk are walked again by one lane each,
+// which writes their rows of the result arrays in the reference's call order and lists their calls.  Rare
+// by construction (no shipped model produces one on any test corpus), hence the host round trips.
+static int run_exact(dtk_batch *b) {
+  const dtk_model *m = b->last_model;
+  hipStream_t s = b->stream;
+  const uint32_t nd = b->n_docs;
+  std::vector<uint32_t> st(nd);
+  HIP_TRY(hipMemcpy(st.data(), b->d_status, (size_t)nd * 4, hipMemcpyDeviceToHost));
+  for (uint32_t d = 0; d < nd; d++)
+    if (st[d] & ST_IRREGULAR) b->h_exact_ids.push_back(d);
+  const uint32_t n = (uint32_t)b->h_exact_ids.size();
+  if (n == 0) return DTK_OK;
+  if (n > b->exact_cap) {
+    void *old[] = {b->d_exact_ids, b->d_exact_cnt, b->d_exact_off};
+    for (void *p : old)
+      if (p) HIP_TRY(hipFree(p));
+    b->d_exact_ids = b->d_exact_cnt = nullptr; b->d_exact_off = nullptr; b->exact_cap = 0;
+    const uint64_t cap = (uint64_t)n + n / 4 + 16;
+    HIP_TRY(hipMalloc((void **)&b->d_exact_ids, cap * 4));
+    HIP_TRY(hipMalloc((void **)&b->d_exact_cnt, cap * 4));
+    HIP_TRY(hipMalloc((void **)&b->d_exact_off, (cap + 1) * 8));
+    b->exact_cap = (uint32_t)cap;
+  }
+  HIP_TRY(hipMemcpy(b->d_exact_ids, b->h_exact_ids.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+  DtkExactArgs X{};
+  X.sym = b->d_sym; X.text = b->d_text; X.doc_off = b->d_off; X.n = n; X.docs = b->d_exact_ids;
+  X.n_calls = b->d_exact_cnt; X.call_off = b->d_exact_off; X.status = b->d_status;
+  X.flags = b->last_flags & DTK_NEWLINE_AFTER_EOT; X.step_factor = walk_args(b).step_factor;
+  X.tok_off = b->d_tok_off; X.sent_off = b->d_sent_off; X.text_off = b->d_text_off;
+  X.tok_rstart = b->d_rstart; X.tok_rend = b->d_rend; X.tok_bstart = b->d_bstart; X.tok_bend = b->d_bend;
+  X.sent = b->d_sent; X.text_tok_end = b->d_ttok; X.text_sent_end = b->d_tsent;
+  const bool ro = (b->last_flags & DTK_OFFSETS_ONLY) != 0;
+  X.tok_sbefore = ro ? nullptr : b->d_sbefore; X.text_s_end = ro ? nullptr : b->d_ts_end;
+  X.doc_ns = ro ? nullptr : b->d_doc_ns;
+  X.pass = 0;
+  if (dtk_launch_exact(&m->tab, &X, s)) return hip_fail(hipGetLastError(), "exact pass (count)");
+  std::vector<uint32_t> cnt(n);
+  HIP_TRY(hipMemcpyAsync(cnt.data(), b->d_exact_cnt, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  b->h_exact_off.assign((size_t)n + 1, 0);
+  for (uint32_t i = 0; i < n; i++) b->h_exact_off[i + 1] = b->h_exact_off[i] + cnt[i];
+  const uint64_t total = b->h_exact_off[n];
+  if (total > b->calls_cap) {
+    if (b->d_calls) HIP_TRY(hipFree(b->d_calls));
+    b->d_calls = nullptr; b->calls_cap = 0;
+    HIP_TRY(hipMalloc((void **)&b->d_calls, (total + total / 4 + 16) * sizeof(DtkCall)));
+    b->calls_cap = total + total / 4 + 16;
+  }
+  HIP_TRY(hipMemcpy(b->d_exact_off, b->h_exact_off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice));
+  X.calls = b->d_calls;
+  X.pass = 1;
+  if (dtk_launch_exact(&m->tab, &X, s)) return hip_fail(hipGetLastError(), "exact pass");
+  b->h_calls.resize((size_t)total);
+  if (total) HIP_TRY(hipMemcpyAsync(b->h_calls.data(), b->d_calls, (size_t)total * sizeof(DtkCall), hipMemcpyDeviceToHost, s));
+  // the documents' status words were rewritten: count the flagged ones again
+  HIP_TRY(hipMemcpyAsync(st.data(), b->d_status, (size_t)nd * 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  uint64_t flagged = 0;
+  for (uint32_t d = 0; d < nd; d++) flagged += st[d] != 0;
+  b->h_totals[3] = flagged;
+  return DTK_OK;
+}
+
 // Reads the totals; if pass 2 found its arrays too small, grows them and runs
 // pass 2 again (the only allocation that can follow a run).
 static int finish(dtk_batch *b) {
@@ -1228,6 +1309,7 @@ static int finish(dtk_batch *b) {
     int rc = launch_compact2(b);
     if (rc != DTK_OK) return rc;
     HIP_TRY(hipMemcpyAsync(b->h_totals, b->d_totals, 5 * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(b->h_totals + 7, b->d_totals + 7, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
   }
   const uint64_t nt = b->h_totals[0], ns = b->h_totals[1], nx = b->h_totals[2];
@@ -1238,6 +1320,12 @@ static int finish(dtk_batch *b) {
     rc = launch_compact2(b);
     if (rc != DTK_OK) return rc;
     HIP_TRY(hipStreamSynchronize(b->stream));
+  }
+  // documents whose calls are not in position order (ST_IRREGULAR): their rows come from the exact pass
+  b->h_exact_ids.clear(); b->h_exact_off.assign(1, 0); b->h_calls.clear();
+  if ((uint32_t)b->h_totals[7] != 0) {
+    int rc = run_exact(b);
+    if (rc != DTK_OK) return rc;
   }
   b->totals.n_docs = b->n_docs;
   b->totals.n_bytes = b->total;
@@ -1278,6 +1366,8 @@ extern "C" int dtk_batch_result_device(dtk_batch *b, dtk_result_view *o) {
   o->tok_bstart = b->d_bstart; o->tok_bend = b->d_bend;
   o->sent = b->d_sent; o->text_tok_end = b->d_ttok; o->text_sent_end = b->d_tsent;
   o->status = b->d_status; o->events = b->d_evA; o->events_open = b->d_evB;
+  o->n_exact = (uint32_t)b->h_exact_ids.size();
+  o->exact_doc = b->d_exact_ids; o->exact_off = b->d_exact_off; o->calls = (const dtk_call *)b->d_calls;
   return DTK_OK;
 }
 
@@ -1309,6 +1399,8 @@ extern "C" int dtk_batch_result_host(dtk_batch *b, dtk_result_view *o) {
   o->tok_bstart = b->h_bstart.data(); o->tok_bend = b->h_bend.data();
   o->sent = b->h_sent.data(); o->text_tok_end = b->h_ttok.data(); o->text_sent_end = b->h_tsent.data();
   o->status = b->h_status.data(); o->events = b->h_events.data(); o->events_open = b->h_events_b.data();
+  o->n_exact = (uint32_t)b->h_exact_ids.size();
+  o->exact_doc = b->h_exact_ids.data(); o->exact_off = b->h_exact_off.data(); o->calls = (const dtk_call *)b->h_calls.data();
   return DTK_OK;
 }
 
@@ -1349,9 +1441,9 @@ static int render(dtk_batch *b, uint32_t bits) {
   R.tx_base = q; q += nx + 1; R.tx_stream = q; q += nx + 1; R.tx_pos = q; q += nx + 1; R.tx_sent = q; q += nx + 1;
   R.out_off = b->d_out_off;
   if (dtk_launch_render(&R, 0, s)) return hip_fail(hipGetLastError(), "render sizes");
-  HIP_TRY(hipMemcpyAsync(b->h_totals + 7, R.tx_base + nx, 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(b->h_totals + 8, R.tx_base + nx, 8, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
-  const uint64_t total = b->h_totals[7];
+  const uint64_t total = b->h_totals[8];
   if (total > b->out_cap) {
     if (b->d_out) HIP_TRY(hipFree(b->d_out));
     b->d_out = nullptr; b->out_cap = 0;

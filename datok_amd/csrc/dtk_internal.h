@@ -187,6 +187,7 @@ struct DtkCompactArgs {
   struct DtkSegSum *seg_sum;              // k_seg_sum: what a segment adds
   struct DtkSegIn *seg_in;                // k_seg_scan: the carries a segment starts with
   uint32_t *doc_seq;                      // k_seg_scan: 1 = this long document must be compacted sequentially
+  uint32_t *any_irregular;                // set to 1 if a document is flagged ST_IRREGULAR (the host then runs the exact pass)
 };
 
 #define DTK_SEG_LANES 64u
@@ -201,6 +202,33 @@ struct DtkSegSum {
 struct DtkSegIn {
   uint32_t tok, sent, text, sev, runes;
   uint32_t e_pos, e_tok, e_runes;  // last EOT TextEnd before the segment (absolute), 0xFFFFFFFF: none
+};
+
+// ---- the exact pass: documents whose call order the position-indexed event bytes cannot express
+// (ST_IRREGULAR: the double array consuming one EOT twice after a backtrack, datok.go:916-926 +
+// 1019-1030; a third epsilon SentenceEnd at one cursor, matrix.go:573-576) are walked again by one
+// lane each, in the reference's own order, writing their rows of the result arrays directly and
+// listing their calls (dtk_call of datok_gpu.h) for closure replays.
+struct DtkCall { uint32_t kind; int32_t a; uint32_t b, c; };
+struct DtkExactArgs {
+  const uint16_t *sym;
+  const uint8_t *text;
+  const uint64_t *doc_off;
+  uint32_t n;               // documents to walk
+  const uint32_t *docs;     // their ids
+  uint32_t pass;            // 0: count the calls (n_calls[i]); 1: write rows and calls
+  uint32_t *n_calls;        // [n]
+  const uint64_t *call_off; // [n + 1], pass 1: calls of docs[i] at calls[call_off[i] ..)
+  struct DtkCall *calls;
+  uint32_t *status;
+  uint32_t flags;           // DTK_NEWLINE_AFTER_EOT
+  uint32_t step_factor;
+  const uint64_t *tok_off, *sent_off, *text_off;  // CSR rows (sized by the walk's counts)
+  int32_t *tok_rstart, *tok_rend;
+  uint32_t *tok_bstart, *tok_bend;
+  int32_t *sent;
+  uint32_t *text_tok_end, *text_sent_end;
+  uint32_t *tok_sbefore, *text_s_end, *doc_ns;    // renderer bookkeeping (may be null)
 };
 
 // NewTokenWriter's byte output on the device (dtk_render.hip)
@@ -243,6 +271,7 @@ int dtk_launch_spec(const struct DtkTableDev *tab, const struct DtkWalkArgs *arg
 int dtk_launch_redo_clear(const struct DtkWalkArgs *args, const struct DtkSpecArgs *spec, const uint32_t *blk_doc,
                           uint64_t total, void *stream);
 int dtk_launch_compact(const struct DtkCompactArgs *args, int pass, void *stream);
+int dtk_launch_exact(const struct DtkTableDev *tab, const struct DtkExactArgs *args, void *stream);
 int dtk_launch_seg_prepare(const struct DtkCompactArgs *args, const uint32_t *doc_seg0, void *stream);
 int dtk_launch_render(const struct DtkRenderArgs *args, int stage, void *stream);
 uint32_t dtk_render_tiles(uint64_t n);

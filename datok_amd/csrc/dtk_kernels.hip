@@ -440,8 +440,9 @@ struct EventSink {
 
   // Token(bufft, buffer[:buffc]) -- matrix.go:528,569,675
   // sent_first: no token since the last SentenceEnd / TextEnd (the writer's sentB)
+  // (bs: byte position of buffer[0], the last rewind -- only the exact pass, ExactSink, needs it)
   template <bool IS_MATRIX>
-  __device__ __forceinline__ void token(uint32_t tp, uint32_t p, bool sent_first) {
+  __device__ __forceinline__ void token(uint32_t /*bs*/, uint32_t tp, uint32_t p, bool sent_first) {
     if (!in_closing(p)) { dropped = 1; return; }
     c_tok++;
     c_sent += sent_first ? 1u : 0u;
@@ -458,7 +459,7 @@ struct EventSink {
   // SentenceEnd? + TextEnd fired by an EOT rune -- matrix.go:593-600
   // has_tok: the current text has a token (else the reference panics in position modes)
   template <bool IS_MATRIX>
-  __device__ __forceinline__ void eot(uint32_t p, bool with_sentence, bool has_tok) {
+  __device__ __forceinline__ void eot(uint32_t /*bs*/, uint32_t p, bool with_sentence, bool has_tok) {
     if (!in_closing(p)) { dropped = 1; return; }
     c_text++;
     c_sev += with_sentence ? 1u : 0u;
@@ -471,7 +472,8 @@ struct EventSink {
     put(0u, p, bits);
   }
   // SentenceEnd from an epsilon arc on an empty token -- matrix.go:574-575
-  __device__ __forceinline__ void sentence(uint32_t p, bool has_tok) {
+  template <bool IS_MATRIX>
+  __device__ __forceinline__ void sentence(uint32_t /*bs*/, uint32_t p, bool has_tok) {
     if (!in_opening(p)) { dropped = 1; return; }
     c_sev++;
     if (has_tok) c_sent++; else st |= ST_EMPTY_TEXT;
@@ -485,7 +487,8 @@ struct EventSink {
     put(1u, p, s_bits);
   }
   // final SentenceEnd / TextEnd -- matrix.go:683-691
-  __device__ __forceinline__ void tail(uint32_t p, bool sentence_end, bool text_end, bool has_tok) {
+  template <bool IS_MATRIX>
+  __device__ __forceinline__ void tail(uint32_t /*bs*/, uint32_t p, bool sentence_end, bool text_end, bool has_tok) {
     const uint32_t bits = (sentence_end ? 0u : EV_S_EOF) | (text_end ? 0u : EV_E_EOF);
     if (!bits) return;
     if (!in_opening(p)) { dropped = 1; return; }
@@ -540,10 +543,10 @@ __device__ __forceinline__ void win_fill(dtk_u16a *row, const uint16_t *__restri
 // positions of buffer[buffc] / buffer[bufft] / buffer[0] / buffer[buffi], and the
 // symbol stream (read through the lane's window in LDS) replaces the rune -> symbol lookups
 // of matrix.go:421-435.
-template <typename TRANS, bool IS_MATRIX, int MODE>
+template <typename TRANS, bool IS_MATRIX, int MODE, typename SINK = EventSink>
 __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__restrict__ sym_base,
                                           uint64_t off, uint32_t len, DtkLaneState init, uint32_t stop_pos,
-                                          EventSink &sink, uint32_t epsilon, uint32_t unknown,
+                                          SINK &sink, uint32_t epsilon, uint32_t unknown,
                                           uint32_t identity, uint32_t cap, DtkLaneState &fin,
                                           uint32_t &st_out, uint32_t &steps_out, uint16_t *win_row) {
   // the lane's window of the symbol stream in LDS: entries (pos + o7) in [wbase, wbase + DTK_WIN)
@@ -653,8 +656,8 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
     const bool flush = flush_eps || hardfail || flush_c;
     if (MODE != MODE_START) {
       if (flush)  // matrix.go:528 / 569
-        sink.template token<IS_MATRIX>(tp, p, sentence_end || text_end || !any_tok);
-      if (sent_eps || sent_c) sink.sentence(p, has_tok);  // matrix.go:575
+        sink.template token<IS_MATRIX>(bs, tp, p, sentence_end || text_end || !any_tok);
+      if (sent_eps || sent_c) sink.template sentence<IS_MATRIX>(bs, p, has_tok);  // matrix.go:575
     }
     any_tok = any_tok || flush;
     has_tok = has_tok || flush;
@@ -688,7 +691,8 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
     const bool long_win = hi - bs > DTK_WINDOW_BYTES;  // overflowed for certain: the lane stops (see walk_fused)
     if (eot_now || (rewind && hi - bs > DTK_WINDOW) || (rewind_end && MODE != MODE_DOC && p >= stop_pos) || long_win) {
       if (eot_now) {
-        if (MODE != MODE_START) sink.template eot<IS_MATRIX>(p, eot_sent, has_tok);
+        // (the epsilon half of a fused cell has rewound the window to p_old before its rune was read)
+        if (MODE != MODE_START) sink.template eot<IS_MATRIX>(flush_c ? p_old : bs, p, eot_sent, has_tok);
         has_tok = false;  // TextEnd: pos = pos[:0] (token_writer.go:158)
       }
       if (rewind) {
@@ -712,11 +716,11 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
     if (hi - bs > DTK_WINDOW && count_runes(s, bs, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
     if (MODE != MODE_START) {
       if (p > tp) {  // matrix.go:671-678
-        sink.template token<IS_MATRIX>(tp, p, sentence_end || text_end || !any_tok);
+        sink.template token<IS_MATRIX>(bs, tp, p, sentence_end || text_end || !any_tok);
         sentence_end = false; text_end = false;
         has_tok = true;
       }
-      sink.tail(p, sentence_end, text_end, has_tok);  // matrix.go:683-691
+      sink.template tail<IS_MATRIX>(bs, p, sentence_end, text_end, has_tok);  // matrix.go:683-691
     }
   }
   st_out = st;
@@ -814,8 +818,8 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
     const bool backtrack = fail && !r && eps_t != 0;    // matrix.go:487-497
     const bool hardfail = fail && !backtrack;
     if (MODE != MODE_START) {
-      if (flush) sink.template token<true>(tp, p, ((F ^ 4u) & 7u) != 0);
-      if (sentE) sink.sentence(p, (F & 8u) != 0);
+      if (flush) sink.template token<true>(bs, tp, p, ((F ^ 4u) & 7u) != 0);
+      if (sentE) sink.template sentence<true>(bs, p, (F & 8u) != 0);
     }
     const uint32_t bs_old = bs;
     F = flush ? ((F & ~3u) | 12u) : (sentE ? (F | 1u) : F);
@@ -854,7 +858,7 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
             if (iw >= DTK_WIN) { wbase = (p + o7) & ~7u; win_fill(row, aligned, wbase); iw = (p + o7) & 7u; }
             e_next = row[iw];
           }
-          if (MODE != MODE_START) sink.template token<true>(tp, p, ((F ^ 4u) & 7u) != 0);
+          if (MODE != MODE_START) sink.template token<true>(bs, tp, p, ((F ^ 4u) & 7u) != 0);
           F = 12u;
           if (hi - bs > DTK_WINDOW && count_runes(s, bs, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
           t = tr.start; eps_t = 0;
@@ -868,7 +872,7 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
       }
       if (over && count_runes(s, bs_old, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
       if (eot_now) {
-        if (MODE != MODE_START) sink.template eot<true>(p, (F & 1u) == 0u, (F & 8u) != 0);
+        if (MODE != MODE_START) sink.template eot<true>(bs, p, (F & 1u) == 0u, (F & 8u) != 0);
         F = (F & 4u) | 3u;  // sentenceEnd, textEnd; TextEnd: pos = pos[:0] (token_writer.go:158)
         eps_t = 0;          // matrix.go:601 rewinds
         if (hi - bs > DTK_WINDOW && count_runes(s, bs, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
@@ -893,10 +897,10 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
     if (hi - bs > DTK_WINDOW && count_runes(s, bs, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
     if (MODE != MODE_START) {
       if (p > tp) {  // matrix.go:671-678
-        sink.template token<true>(tp, p, ((F ^ 4u) & 7u) != 0);
+        sink.template token<true>(bs, tp, p, ((F ^ 4u) & 7u) != 0);
         F = (F & ~3u) | 8u;
       }
-      sink.tail(p, (F & 1u) != 0, (F & 2u) != 0, (F & 8u) != 0);  // matrix.go:683-691
+      sink.template tail<true>(bs, p, (F & 1u) != 0, (F & 2u) != 0, (F & 8u) != 0);  // matrix.go:683-691
     }
   }
   if (MODE != MODE_START) sink.flush();
@@ -928,6 +932,133 @@ __device__ __forceinline__ void add_steps(unsigned long long *counter, uint32_t 
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) tot += __shfl_down(tot, o);
   if (lane_id() == 0 && tot) atomicAdd(counter, tot);
+}
+
+// ---- the exact pass: one lane per irregular document ----
+//
+// NewTokenWriter (token_writer.go:36-175) with TOKEN_POS | SENTENCE_POS semantics, fed by the walk in the
+// reference's own call order: what the compaction derives from position-indexed event bytes for every
+// other document.  Writes the document's rows of the result arrays and, call by call, the list a closure
+// replay needs (kind 0 Token: a = byte position of buffer[0], b = of buffer[offset], c = end;
+// kind 1 SentenceEnd(a); kind 2 TextEnd(a) -- the int arguments as upstream: matrix.go:575,597,600,684,691
+// pass buffc, datok.go:1015,1026,1119,1127 pass 0 and only :1023 buffc).
+struct ExactSink {
+  const uint16_t *s;   // the document's symbol stream (bit 15: rune start)
+  const uint8_t *txt;  // the document's bytes
+  bool nl_rule, write;
+  DtkCall *log;
+  int32_t *rstart, *rend, *sent;
+  uint32_t *bstart, *bend, *ttok, *tsent, *sbefore, *ts_end;
+  uint32_t tok_n, sent_n, text_n;  // row lengths
+  // token_writer.go:38-42
+  int32_t posC, last_rend;
+  bool init, sentB;
+  uint32_t n_tok, n_sent, n_text, n_sev, text_tok0, n_calls;
+  uint32_t st;
+  __device__ __forceinline__ void start() {
+    posC = 0; last_rend = 0; init = true; sentB = true;
+    n_tok = n_sent = n_text = n_sev = text_tok0 = n_calls = 0; st = 0;
+  }
+  __device__ __forceinline__ int32_t runes(uint32_t from, uint32_t to) const {
+    return to > from ? (int32_t)count_runes(s, from, to) : 0;
+  }
+  __device__ __forceinline__ void call(uint32_t kind, int32_t a, uint32_t b, uint32_t c) {
+    if (write) log[n_calls] = DtkCall{kind, a, b, c};
+    n_calls++;
+  }
+  __device__ __forceinline__ void push_sent(int32_t v) {
+    if (write) { if (n_sent < sent_n) sent[n_sent] = v; else st |= ST_INTERNAL; }
+    n_sent++;
+  }
+  __device__ __forceinline__ void sentence_end(int32_t arg) {  // token_writer.go:104-115
+    call(1u, arg, 0u, 0u);
+    n_sev++;
+    if (n_tok == text_tok0) st |= ST_EMPTY_TEXT; else push_sent(last_rend);
+    sentB = true;
+  }
+  __device__ __forceinline__ void text_end(int32_t arg) {  // token_writer.go:131-159
+    call(2u, arg, 0u, 0u);
+    if (n_tok == text_tok0) st |= ST_EMPTY_TEXT;
+    if (write) {
+      if (n_text < text_n) {
+        ttok[n_text] = n_tok; tsent[n_text] = n_sent;
+        if (ts_end) ts_end[n_text] = n_sev;
+      } else st |= ST_INTERNAL;
+    }
+    n_text++;
+    sentB = true; posC = 0; text_tok0 = n_tok;
+  }
+  template <bool IS_MATRIX>
+  __device__ __forceinline__ void token(uint32_t bs, uint32_t tp, uint32_t p, bool) {  // token_writer.go:58-88
+    call(0u, (int32_t)bs, tp, p);
+    const int32_t off_r = runes(bs, tp), len_r = runes(bs, p);  // offset, len(buf)
+    if (posC == 0 && nl_rule && p > bs && txt[bs] == '\n' && !init) posC--;  // :66-68
+    init = false;
+    posC += off_r;
+    const int32_t rs = posC;
+    if (sentB) { sentB = false; push_sent(rs); }
+    posC += len_r - off_r;
+    last_rend = posC;
+    if (write) {
+      if (n_tok < tok_n) {
+        rstart[n_tok] = rs; rend[n_tok] = posC;
+        bstart[n_tok] = tp < p ? tp : p; bend[n_tok] = p;  // an empty surface: the empty range at the end of the buffer
+        if (sbefore) sbefore[n_tok] = n_sev;
+      } else st |= ST_INTERNAL;
+    }
+    n_tok++;
+  }
+  template <bool IS_MATRIX>
+  __device__ __forceinline__ void eot(uint32_t bs, uint32_t p, bool with_sentence, bool) {
+    const int32_t buffc = runes(bs, p);
+    if (with_sentence) sentence_end(buffc);      // matrix.go:597 / datok.go:1023
+    text_end(IS_MATRIX ? buffc : 0);             // matrix.go:600 / datok.go:1026
+  }
+  template <bool IS_MATRIX>
+  __device__ __forceinline__ void sentence(uint32_t bs, uint32_t p, bool) {
+    sentence_end(IS_MATRIX ? runes(bs, p) : 0);  // matrix.go:575 / datok.go:1015
+  }
+  template <bool IS_MATRIX>
+  __device__ __forceinline__ void tail(uint32_t bs, uint32_t p, bool sentence_end_, bool text_end_, bool) {
+    const int32_t arg = IS_MATRIX ? runes(bs, p) : 0;
+    if (!sentence_end_) sentence_end(arg);       // matrix.go:683-684 / datok.go:1118-1119
+    if (!text_end_) text_end(arg);               // matrix.go:690-691 / datok.go:1126-1127
+  }
+};
+
+template <typename TRANS, bool IS_MATRIX>
+__global__ __launch_bounds__(WAVE) void k_exact_doc(TRANS tr, DtkExactArgs X, uint32_t epsilon, uint32_t unknown,
+                                                    uint32_t identity) {
+  __shared__ uint16_t s_win[WAVE * DTK_WIN_ROW];
+  uint16_t *win_row = s_win + threadIdx.x * DTK_WIN_ROW;
+  const uint32_t i = blockIdx.x * WAVE + threadIdx.x;
+  if (i >= X.n) return;
+  const uint32_t d = X.docs[i];
+  const uint64_t off = X.doc_off[d];
+  const uint32_t len = (uint32_t)(X.doc_off[d + 1] - off);
+  ExactSink sink;
+  sink.s = X.sym + off; sink.txt = X.text + off;
+  sink.nl_rule = (X.flags & 16u) != 0; sink.write = X.pass != 0;
+  sink.log = X.pass ? X.calls + X.call_off[i] : nullptr;
+  const uint64_t t0 = X.tok_off[d], s0 = X.sent_off[d], x0 = X.text_off[d];
+  sink.rstart = X.tok_rstart + t0; sink.rend = X.tok_rend + t0;
+  sink.bstart = X.tok_bstart + t0; sink.bend = X.tok_bend + t0;
+  sink.sbefore = X.tok_sbefore ? X.tok_sbefore + t0 : nullptr;
+  sink.sent = X.sent + s0;
+  sink.ttok = X.text_tok_end + x0; sink.tsent = X.text_sent_end + x0;
+  sink.ts_end = X.text_s_end ? X.text_s_end + x0 : nullptr;
+  sink.tok_n = (uint32_t)(X.tok_off[d + 1] - t0); sink.sent_n = (uint32_t)(X.sent_off[d + 1] - s0);
+  sink.text_n = (uint32_t)(X.text_off[d + 1] - x0);
+  sink.start();
+  DtkLaneState init{0u, tr.start_state(), tr.start_aux(), 0u}, fin;
+  uint32_t st = 0, steps = 0;
+  walk_lane<TRANS, IS_MATRIX, MODE_DOC, ExactSink>(tr, X.sym, off, len, init, 0u, sink, epsilon, unknown, identity,
+                                                   step_cap(X.step_factor, len), fin, st, steps, win_row);
+  if (X.pass == 0) { X.n_calls[i] = sink.n_calls; return; }
+  // the rows were sized by the first walk's counts: both walks make the same calls
+  if (sink.n_tok != sink.tok_n || sink.n_sent != sink.sent_n || sink.n_text != sink.text_n) st |= ST_INTERNAL;
+  X.status[d] = st | sink.st;
+  if (X.doc_ns) X.doc_ns[d] = sink.n_sev;
 }
 
 // ---- one document per lane (no speculation) ----
@@ -1421,6 +1552,11 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
   const bool is_matrix = A.kind == DTK_KIND_MATRIX;
   const uint32_t lane = lane_id();
   const unsigned long long lt = lanemask_lt();
+  // a document whose calls are not in position order: its rows are written by the exact pass (k_exact_doc)
+  if (A.status[d] & ST_IRREGULAR) {
+    if (lane == 0) atomicOr(A.any_irregular, 1u);
+    return;
+  }
 
   // rows were sized by the walk's counts + scan; skip everything if the output arrays
   // are too small (the host grows them and re-launches this pass)
@@ -2022,6 +2158,24 @@ extern "C" int dtk_launch_redo_clear(const DtkWalkArgs *args, const DtkSpecArgs 
   const uint32_t blocks = (uint32_t)((total + DTK_SYM_BLOCK_BYTES - 1) / DTK_SYM_BLOCK_BYTES);
   hipLaunchKernelGGL(k_redo_clear, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *args, *spec, blk_doc, total);
   return (int)hipGetLastError();
+}
+
+// the exact pass over the listed documents (one lane each; the general loop for every table kind)
+extern "C" int dtk_launch_exact(const DtkTableDev *tab, const DtkExactArgs *args, void *stream) {
+  if (args->n == 0) return 0;
+  const uint32_t blocks = (args->n + WAVE - 1) / WAVE;
+  hipStream_t s = (hipStream_t)stream;
+  return with_trans(tab, [&](auto tr, auto is_matrix) {
+    using TR = decltype(tr);
+    if constexpr (TR::LEAN) {
+      const MatrixFusedTrans base = tr;
+      hipLaunchKernelGGL((k_exact_doc<MatrixFusedTrans, true>), dim3(blocks), dim3(WAVE), 0, s, base, *args,
+                         tab->epsilon, tab->unknown, tab->identity);
+    } else {
+      hipLaunchKernelGGL((k_exact_doc<TR, decltype(is_matrix)::value>), dim3(blocks), dim3(WAVE), 0, s, tr, *args,
+                         tab->epsilon, tab->unknown, tab->identity);
+    }
+  });
 }
 
 extern "C" int dtk_launch_compact(const DtkCompactArgs *args, int pass, void *stream) {

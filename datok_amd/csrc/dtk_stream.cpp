@@ -97,8 +97,7 @@ extern "C" int dtk_transduce_replay(const dtk_model *m, const uint8_t *text, siz
     return rc;
   std::ostringstream os;
   auto tw = datok::NewTokenWriter(os, (datok::Bits)bits);
-  datok::detail::replay(std::strcmp(dtk_model_type(m), "MATOK") == 0, text, n, v.events, v.events_open,
-                        v.tok_bstart, *tw);
+  datok::detail::replay_view(std::strcmp(dtk_model_type(m), "MATOK") == 0, text, n, v, *tw);
   tw->Flush();
   if (status) {
     // an empty text only breaks the position modes (token_writer.go:108,135,145)

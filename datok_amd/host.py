@@ -162,6 +162,36 @@ def replay(is_matrix, text: bytes, events, tok_bstart, tw: TokenWriter):
             tw.TextEnd(buffc() if is_matrix else 0)
 
 
+def replay_calls(text: bytes, calls, tw: TokenWriter):
+    """Feeds the call list of a document walked by the exact pass (dtk_result_view.calls: rows of
+    (kind, a, b, c)) to the closures: kind 0 Token(offset, buf) with buf = runes of text[a:c] and offset =
+    runes of text[a:b]; kind 1 SentenceEnd(a); kind 2 TextEnd(a)."""
+    for kind, a, b, c in calls:
+        if kind == 0:
+            tw.Token(len(_decode_runes(text[a:b])), _decode_runes(text[a:c]))
+        elif kind == 1:
+            tw.SentenceEnd(a)
+        else:
+            tw.TextEnd(a)
+
+
+def _exact_calls(v, arr):
+    """dict doc id -> list of (kind, a, b, c) from a host dtk_result_view."""
+    n = int(v.n_exact)
+    if n == 0:
+        return {}
+    ids = arr(v.exact_doc, n, np.uint32)
+    off = arr(v.exact_off, n + 1, np.uint64)
+    calls = arr(v.calls, int(off[-1]) * 4, np.int32).reshape(-1, 4)
+    return {int(ids[i]): [(int(k) & 0xFFFFFFFF, int(a), int(b) & 0xFFFFFFFF, int(c) & 0xFFFFFFFF)
+                          for k, a, b, c in calls[int(off[i]):int(off[i + 1])]] for i in range(n)}
+
+
+# statuses on which the reference cannot finish a document whatever the writer does (matrix.go:365,406 index
+# panic; a walk that left the table; the lookup cap; an internal check): TransduceTokenWriter returns false
+_FATAL = _lib.ST_WINDOW_OVERFLOW | _lib.ST_BAD_MODEL | _lib.ST_STEP_LIMIT | _lib.ST_INTERNAL | _lib.ST_IRREGULAR
+
+
 # ------------------------------------------------------------------- Tokenizer
 class Tokenizer:
     """fomafile.go:29-33 Tokenizer, backed by a device-resident model."""
@@ -201,11 +231,15 @@ class Tokenizer:
 
         def arr(ptr, n, dt):
             return np.frombuffer((C.c_char * (n * np.dtype(dt).itemsize)).from_address(ptr), dtype=dt) if n else np.zeros(0, dt)
-        events = (arr(v.events, n_ev, np.uint8) & np.uint8(7)) | arr(v.events_open, n_ev, np.uint8)
         self.last_status = int(arr(v.status, 1, np.uint32)[0])
-        replay(self.type() == "MATOK", text, events, arr(v.tok_bstart, ntok, np.uint32), tw)
+        exact = _exact_calls(v, arr)
+        if 0 in exact:                          # walked by the exact pass: its calls are listed in order
+            replay_calls(text, exact[0], tw)
+        else:
+            events = (arr(v.events, n_ev, np.uint8) & np.uint8(7)) | arr(v.events_open, n_ev, np.uint8)
+            replay(self.type() == "MATOK", text, events, arr(v.tok_bstart, ntok, np.uint32), tw)
         tw.Flush()                              # `defer w.Flush()`, matrix.go:374
-        return True
+        return not (self.last_status & _FATAL)
 
     def transduce_bytes(self, text: bytes, flags=SIMPLE, replay=False):
         """dtk_transduce(): walked and rendered on the device; replay=True: dtk_transduce_replay(), the
@@ -240,7 +274,7 @@ def event_base(doc_off_d, d):
 class BatchResult:
     """Host copy of dtk_result_view (CSR over documents)."""
     __slots__ = ("tok_off", "sent_off", "text_off", "tok_rstart", "tok_rend", "tok_bstart",
-                 "tok_bend", "sent", "text_tok_end", "text_sent_end", "status", "events", "doc_off")
+                 "tok_bend", "sent", "text_tok_end", "text_sent_end", "status", "events", "doc_off", "exact")
 
     def doc(self, d):
         a, b = int(self.tok_off[d]), int(self.tok_off[d + 1])
@@ -377,6 +411,7 @@ class Batch:
         # closing events are the low three bits of `events` (the rest is a length field of the device compaction)
         r.events = (arr(v.events, n_ev, np.uint8) & np.uint8(7)) | arr(v.events_open, n_ev, np.uint8)
         r.doc_off = self._doc_off
+        r.exact = _exact_calls(v, arr)   # documents walked by the exact pass: id -> calls in order
         return r
 
 

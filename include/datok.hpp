@@ -144,6 +144,42 @@ inline void replay(bool is_matrix, const uint8_t *text, size_t n, const uint8_t 
   }
 }
 
+// The same for a document walked by the exact pass (dtk_result_view.calls): the calls are listed in
+// the reference's order with their arguments.
+inline void replay_calls(const uint8_t *text, size_t n, const dtk_call *calls, size_t n_calls, TokenWriter &w) {
+  std::vector<rune> buf;
+  for (size_t k = 0; k < n_calls; k++) {
+    const dtk_call &c = calls[k];
+    if (c.kind == 0) {
+      buf.clear();
+      int offset = 0;
+      size_t i = (size_t)c.a;
+      while (i < c.c && i < n) {
+        rune r;
+        int wd = decode_rune(text + i, n - i, &r);
+        if (i < c.b) offset++;
+        buf.push_back(r);
+        i += (size_t)wd;
+      }
+      if (c.b > c.c) offset += count_runes(text + c.c, (c.b < n ? c.b : n) - c.c);  // DTK_ST_BAD_OFFSET: offset > len(buf)
+      w.Token(offset, buf);
+    } else if (c.kind == 1) {
+      w.SentenceEnd(c.a);
+    } else {
+      w.TextEnd(c.a);
+    }
+  }
+}
+
+// one document of a host dtk_result_view (document 0 of a one-stream batch): event bytes, or the
+// call list if the exact pass walked it
+inline void replay_view(bool is_matrix, const uint8_t *text, size_t n, const dtk_result_view &v, TokenWriter &w) {
+  if (v.n_exact && v.exact_doc[0] == 0)
+    replay_calls(text, n, v.calls + v.exact_off[0], (size_t)(v.exact_off[1] - v.exact_off[0]), w);
+  else
+    replay(is_matrix, text, n, v.events, v.events_open, v.tok_bstart, w);
+}
+
 }  // namespace detail
 
 // token_writer.go:36-175
@@ -278,7 +314,11 @@ class GpuTokenizer final : public Tokenizer {
     const bool ok = dtk_transduce_result(m_, text, n, 0, &v) == DTK_OK;
     if (ok) {
       last_status_ = v.status[0];
-      detail::replay(Type() == "MATOK", text, n, v.events, v.events_open, v.tok_bstart, w);
+      detail::replay_view(Type() == "MATOK", text, n, v, w);
+      // the reference cannot finish such a document whatever the writer does (matrix.go:365,406 index panic,
+      // a walk that left the table): false
+      if (last_status_ & (DTK_ST_WINDOW_OVERFLOW | DTK_ST_BAD_MODEL | DTK_ST_STEP_LIMIT | DTK_ST_INTERNAL | DTK_ST_IRREGULAR))
+        return false;
     }
     return ok;
   }

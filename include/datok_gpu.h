@@ -61,8 +61,8 @@ enum {
   DTK_ST_EMPTY_TEXT = 2,      /* SentenceEnd/TextEnd with no token in the text:
                                  token_writer.go:108,135,145 panic in position modes */
   DTK_ST_BAD_MODEL = 4,       /* walk left the table */
-  DTK_ST_IRREGULAR = 8,       /* >2 sentence ends at one cursor position, or a text end
-                                 revisited (double array + in-document EOT backtrack) */
+  DTK_ST_IRREGULAR = 8,       /* internal: calls not in position order; such a document is re-walked by the
+                                 exact pass (dtk_result_view.n_exact) and never reported with this bit */
   DTK_ST_STEP_LIMIT = 16,     /* safety cap on lookups hit */
   DTK_ST_INTERNAL = 32,       /* internal consistency check failed (a bug; never expected) */
   DTK_ST_BAD_OFFSET = 64      /* a Token call whose offset lies behind its buffer (after a hard fail with the
@@ -185,6 +185,13 @@ int dtk_batch_totals(dtk_batch *b, dtk_totals *out);
  *   status[d]          = DTK_ST_* bits
  * Pointers are DEVICE pointers owned by the batch, valid until the next run.
  */
+/* One call of the reference into the TokenWriter, for documents walked by the exact pass (below):
+ * kind 0 = Token(offset, buf): a = byte position of buf[0], b = of buf[offset], c = end of buf
+ *          (document relative; b > c only in DTK_ST_BAD_OFFSET documents);
+ * kind 1 = SentenceEnd(a);  kind 2 = TextEnd(a) -- a is the int the reference passes
+ *          (matrix.go:575,597,600,684,691: buffc; datok.go:1015,1026,1119,1127: 0, :1023: buffc). */
+typedef struct { uint32_t kind; int32_t a; uint32_t b, c; } dtk_call;
+
 typedef struct {
   const uint64_t *tok_off, *sent_off, *text_off; /* n_docs+1 each */
   const int32_t *tok_rstart, *tok_rend;
@@ -201,6 +208,19 @@ typedef struct {
    * marks its first byte in events_open) -- bookkeeping of the device compaction. */
   const uint8_t *events;
   const uint8_t *events_open;
+  /* The exact pass.  The event bytes order the calls by cursor position.  Two constructs of the
+   * reference break that order: the double array consuming one EOT rune twice (it keeps its window
+   * over an EOT, datok.go:1019-1030, so a later backtrack, :916-926, re-reads it: SentenceEnd /
+   * TextEnd, then a Token that ends BEFORE them, then both again), and more than two epsilon
+   * SentenceEnds at one cursor (matrix.go:573-576 has no limit).  No shipped model does either on
+   * any test corpus; a document that does is walked again by a single lane in the reference's own
+   * order, which writes its rows of the arrays above (bit-exact like all others) and lists its
+   * calls here.  For the n_exact documents exact_doc[i] (ascending) a replay must use
+   * calls[exact_off[i] .. exact_off[i+1]) instead of the event bytes. */
+  uint32_t n_exact;
+  const uint32_t *exact_doc;
+  const uint64_t *exact_off; /* n_exact + 1 */
+  const dtk_call *calls;
 } dtk_result_view;
 int dtk_batch_result_device(dtk_batch *b, dtk_result_view *out);
 /* status words of the first n documents, copied to the caller's array */

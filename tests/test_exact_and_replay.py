@@ -1,0 +1,194 @@
+"""The exact pass (documents whose calls are not in position order) and the closure replay: call order
+and int arguments against the oracle's event list (orc_transduce_events), both encodings.
+
+The crafted tokenizers of tests/craft.py make the reference do what no shipped model does:
+consume one EOT twice (double array, datok.go:916-926 + 1019-1030) and fire three epsilon
+SentenceEnds at one cursor (matrix.go:573-576)."""
+import gzip
+import io
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import craft
+from conftest import MODELS, ROOT
+from parity import assert_batch_equals_oracle
+
+NEWLINE_AFTER_EOT = 16
+
+
+def _oracle(blob):
+    from oracle import oracle as O
+    return O.Model(raw=gzip.decompress(blob))
+
+
+def _oracle_calls(om, doc: bytes):
+    """[('T', offset, len(buf)) | ('S', arg) | ('E', arg)] in the reference's call order."""
+    ev, _ = om.events(doc)
+    out = []
+    for kind, a, b, c, d in ev:
+        if kind == 0:
+            out.append(("T", a, len(doc[b:d].decode("utf-8", "replace")) if d > b else 0, c, d))
+        else:
+            out.append(("SE"[kind - 1], a))
+    return out
+
+
+# ------------------------------------------------------------------ oracle only: the fixtures do what they are for
+def test_crafted_models_break_the_position_order_on_the_oracle():
+    da = _oracle(craft.datok())
+    calls = _oracle_calls(da, b"a\x04a")
+    # SentenceEnd(buffc) + TextEnd(0) for the EOT, THEN the token "a" that ends before the EOT, then both again
+    assert [c[0] for c in calls] == ["S", "E", "T", "S", "E", "T", "S", "E"]
+    assert calls[0] == ("S", 2) and calls[1] == ("E", 0) and calls[2][3:] == (0, 1) and calls[3] == ("S", 1)
+    mx = _oracle(craft.matok())
+    assert [c[0] for c in _oracle_calls(mx, b"a\x04a")] == ["S", "E", "T", "S", "E"]     # matrix.go:601 rewinds: no revisit
+    for blob in (craft.matok(True), craft.datok(True)):
+        calls = _oracle_calls(_oracle(blob), b"a. b")
+        assert [c[0] for c in calls] == ["T", "T", "S", "S", "S", "T", "S", "E"]
+
+
+# ------------------------------------------------------------------------------------------------------- GPU
+class _Recorder:
+    """A custom TokenWriter (token_writer.go:27-33): records every call with its arguments."""
+
+    def __init__(self):
+        self.calls = []
+        self.Token = lambda off, buf: self.calls.append(("T", off, len(buf)))
+        self.SentenceEnd = lambda a: self.calls.append(("S", a))
+        self.TextEnd = lambda a: self.calls.append(("E", a))
+        self.Flush = lambda: None
+
+
+def _replayed(res, d, doc: bytes, is_matrix):
+    import datok_amd
+    from datok_amd import host
+    rec = _Recorder()
+    if d in res.exact:
+        host.replay_calls(doc, res.exact[d], rec)
+    else:
+        base = host.event_base(res.doc_off[d], d)
+        a, b = int(res.tok_off[d]), int(res.tok_off[d + 1])
+        host.replay(is_matrix, doc, res.events[base:base + len(doc) + 1], res.tok_bstart[a:b], rec)
+    return rec.calls
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,triple", [("datok", False), ("matok", False), ("datok", True), ("matok", True)])
+@pytest.mark.parametrize("chunk,flags", [(0, 0), (16, NEWLINE_AFTER_EOT), (None, 0)])
+def test_documents_out_of_position_order_are_exact(tmp_path, kind, triple, chunk, flags):
+    """Offsets, status, call order, int arguments and rendered bytes of EVERY document equal the oracle's;
+    the documents the event bytes cannot express went through the exact pass."""
+    import datok_amd
+    from datok_amd import corpus
+    blob = getattr(craft, kind)(triple)
+    path = tmp_path / ("crafted." + kind)
+    path.write_bytes(blob)
+    tok, om = datok_amd.load_tokenizer_file(str(path)), _oracle(blob)
+    assert tok is not None and tok.type() == kind.upper()
+    docs = craft.documents(np.random.default_rng(5))
+    text, off = corpus.concat_docs(docs)
+    with datok_amd.Batch(max(len(text), 1), len(docs)) as b:
+        if chunk is not None:
+            b.set_chunking(chunk, 8, extend=0)
+        b.set_input(text, off)
+        b.run(tok, flags)
+        res, tot = b.result(), b.totals()
+        assert not any(int(s) & datok_amd.ST_IRREGULAR for s in res.status)
+        assert assert_batch_equals_oracle(om, res, text, off, flags) > 100
+        if kind == "datok" or triple:
+            assert len(res.exact) > 0         # the construct occurred and was handled
+        if kind == "matok" and not triple:
+            assert len(res.exact) == 0        # the matrix rewinds at an EOT: nothing to revisit
+        for d, doc in enumerate(docs):
+            exp = [c[:3] if c[0] == "T" else c for c in _oracle_calls(om, doc)]
+            assert _replayed(res, d, doc, kind == "matok") == exp, (d, doc)
+        # the writer's bytes, rendered on the device from the arrays the exact pass wrote
+        for bits in (3, 15, 5):
+            data, o = b.render(bits | flags)
+            for d, doc in enumerate(docs):
+                exp, est = om.transduce(doc, bits | flags)
+                if est == 0 and not (int(res.status[d]) & ~datok_amd.ST_EMPTY_TEXT):
+                    assert data[int(o[d]):int(o[d + 1])] == exp, (bits, d, doc)
+    # one stream through the drop-in entry points: device rendering, C++ closure replay, Python closure replay
+    for doc in (b"a\x04a", b"a\x04a\x04a\x04a b.", b"a. b.\x04a"):
+        for bits in (3, 3 | flags):
+            exp, est = om.transduce(doc, bits)
+            assert est == 0
+            assert tok.transduce_bytes(doc, bits) == (exp, 0)
+            assert tok.transduce_bytes(doc, bits, replay=True) == (exp, 0)
+        w = io.BytesIO()
+        assert tok.transduce_token_writer(io.BytesIO(doc), datok_amd.new_token_writer(w, 3))
+        assert w.getvalue() == om.transduce(doc, 3)[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["tokenizer_de.matok", "tokenizer_de.datok", "tokenizer_en.matok", "simpletok.datok"])
+def test_closure_int_arguments_equal_the_reference(oracle_models, model):
+    """SentenceEnd / TextEnd ints: the matrix passes buffc everywhere (matrix.go:575,597,600,684,691), the double
+    array 0 (datok.go:1015,1026,1119,1127) except SentenceEnd(buffc) at an EOT (datok.go:1023); Token(offset, buf):
+    offset and len(buf).  Python mirror (closure replay) against orc_transduce_events."""
+    import datok_amd
+    from datok_amd import corpus
+    tok, om = datok_amd.load_tokenizer_file(os.path.join(MODELS, model)), oracle_models(model)
+    text, off = corpus.german_docs(16, 1024, seed=17)
+    raw = text.tobytes()
+    docs = [raw[int(off[d]):int(off[d + 1])] for d in range(16)]
+    docs += ["This.\n\x04And.\n\x04\n".encode(), "\nThis.\n\x04\nAnd.\n\x04\n".encode(), "Erste.\n\n\n\n\x04\nNächst.\x04".encode(),
+             "word\x04 more words. And\x04more".encode(), b"a\x04b\x04c", "„Zitat“ – so … »y« 日本語".encode(), b"", b" ", b"\x04",
+             b"Hallo! " + b"w" * 64 + b" Ende.", b"x" * 40 + b". Und   \n\n weiter ...", b"\xff\xfe bad \x80 bytes \xc3"]
+    n_args = 0
+    for doc in docs:
+        rec = _Recorder()
+        assert tok.transduce_token_writer(io.BytesIO(doc), rec)
+        exp = [c[:3] if c[0] == "T" else c for c in _oracle_calls(om, doc)]
+        assert rec.calls == exp, (model, doc[:60])
+        n_args += sum(1 for c in exp if c[0] != "T" and c[1] != 0)
+    if model.endswith(".matok"):
+        assert n_args > 50       # buffc is rarely 0 for the matrix
+
+
+@pytest.mark.gpu
+def test_closure_int_arguments_cpp_mirror(oracle_models, tmp_path):
+    """The same through include/datok.hpp (TransduceTokenWriter with a custom writer)."""
+    import datok_amd
+    lib = datok_amd.build()
+    src = tmp_path / "args.cpp"
+    src.write_text(r'''
+#include <fstream>
+#include <iostream>
+#include "datok.hpp"
+int main(int argc, char **argv) {
+  auto tok = datok::LoadTokenizerFile(argv[1]);
+  if (!tok) return 3;
+  std::ifstream in(argv[2], std::ios::binary);
+  datok::TokenWriter tw;
+  tw.Token = [&](int off, const std::vector<datok::rune> &buf) { std::cout << "T " << off << " " << buf.size() << "\n"; };
+  tw.SentenceEnd = [&](int a) { std::cout << "S " << a << "\n"; };
+  tw.TextEnd = [&](int a) { std::cout << "E " << a << "\n"; };
+  tw.Flush = [] { return 0; };
+  return tok->TransduceTokenWriter(in, tw) ? 0 : 5;
+}
+''')
+    exe = tmp_path / "args"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           lib, "-Wl,-rpath," + os.path.dirname(lib)])
+    doc = "Der alte Mann. Er ging!\n\x04\nNoch ein Text, z.B. hier.\x04 Ende".encode()
+    inp = tmp_path / "in.txt"
+    inp.write_bytes(doc)
+    models = [(os.path.join(MODELS, m), oracle_models(m)) for m in ("tokenizer_de.matok", "tokenizer_de.datok")]
+    for kind in ("datok", "matok"):                 # and a crafted one whose calls come from the exact pass
+        p = tmp_path / ("crafted." + kind)
+        p.write_bytes(getattr(craft, kind)())
+        models.append((str(p), _oracle(getattr(craft, kind)())))
+    for i, (path, om) in enumerate(models):
+        if i >= 2:
+            inp.write_bytes(b"ab a\x04a\x04a. b\x04ab")
+            doc = inp.read_bytes()
+        r = subprocess.run([str(exe), path, str(inp)], capture_output=True)
+        assert r.returncode == 0, r.stderr
+        got = [tuple([ln.split()[0]] + [int(x) for x in ln.split()[1:]]) for ln in r.stdout.decode().splitlines()]
+        exp = [c[:3] if c[0] == "T" else c for c in _oracle_calls(om, doc)]
+        assert got == exp, path

@@ -140,15 +140,38 @@ def test_config2_german_4096x4096_full(gpu, oracle_models, chunk):
     assert tot["n_tokens"] == int(counts[:, 0].sum())
 
 
-def test_config4_double_array_equals_matrix(gpu, oracle_models):
+def test_config4_double_array_full(gpu, oracle_models):
+    """BASELINE.json configs[3] at its full size: tokenizer_de.datok on the 4096 x 4 KiB batch of config 2 --
+    every field equals the matrix run's (no U+0004 in the corpus, matrix_test.go:1248-1275) and every
+    document equals the oracle's double-array walk."""
     from datok_amd import corpus
-    text, off = corpus.german_docs(1024, 4096, seed=2)
-    rd, _ = run_batch(gpu("tokenizer_de.datok"), text, off)
+    text, off = corpus.german_docs(4096, 4096, seed=2)
+    rd, td = run_batch(gpu("tokenizer_de.datok"), text, off)
     rm, _ = run_batch(gpu("tokenizer_de.matok"), text, off)
+    assert td["n_flagged"] == 0 and td["n_docs"] == 4096
     for f in ("tok_off", "tok_rstart", "tok_rend", "tok_bstart", "tok_bend", "sent_off", "sent",
               "text_tok_end", "text_sent_end", "status"):
         assert np.array_equal(getattr(rd, f), getattr(rm, f)), f
-    assert_batch_equals_oracle(oracle_models("tokenizer_de.datok"), rd, text, off, docs=range(0, 1024, 7))
+    assert assert_batch_equals_oracle(oracle_models("tokenizer_de.datok"), rd, text, off) == 4096
+
+
+def _check_size_independent(res, off, counts):
+    """Properties that hold at any size: per-document token / text counts equal the oracle's counting pass
+    (orc_count_batch), tokens are non-empty, sorted and non-overlapping inside their document, rune offsets
+    never exceed byte offsets."""
+    ntok = np.diff(res.tok_off.astype(np.int64))
+    assert np.array_equal(ntok, counts[:, 0].astype(np.int64))
+    assert np.array_equal(np.diff(res.text_off.astype(np.int64)), counts[:, 2].astype(np.int64))
+    assert np.all(res.tok_bend > res.tok_bstart) and np.all(res.tok_rend > res.tok_rstart)
+    same_doc = np.ones(len(res.tok_bstart) - 1, dtype=bool)
+    first = res.tok_off[1:-1].astype(np.int64)
+    same_doc[first[(first > 0) & (first < len(res.tok_bstart))] - 1] = False
+    assert np.all(res.tok_bstart[1:][same_doc] >= res.tok_bend[:-1][same_doc])
+    doc_len = np.diff(off.astype(np.int64))
+    has = ntok > 0
+    last = (res.tok_off[1:].astype(np.int64) - 1)[has]
+    assert np.all(res.tok_bend[last] <= doc_len[has])
+    assert np.all(res.tok_rend <= res.tok_bend.astype(np.int64))
 
 
 def test_config3_english_zipf(gpu, oracle_models):
@@ -157,6 +180,53 @@ def test_config3_english_zipf(gpu, oracle_models):
     res, tot = run_batch(gpu("tokenizer_en.matok"), text, off)
     assert tot["n_flagged"] == 0
     assert_batch_equals_oracle(oracle_models("tokenizer_en.matok"), res, text, off)
+
+
+def test_config3_english_zipf_full(gpu, oracle_models):
+    """BASELINE.json configs[2] at its full size: 65 536 documents, Zipf lengths 64 B .. 64 KiB (about 294 MB): the
+    multi-block scan, the separate k_spec_fix launch (more than 8192 documents) and the load-balance stress the
+    config exists for.  Every document's counts against the oracle's counting pass, and every offset of 2 112
+    documents -- 64 of the longest (64 KiB) and a seeded random sample -- against the oracle."""
+    from datok_amd import corpus
+    text, off = corpus.english_zipf_docs(65536, seed=3)
+    assert len(off) - 1 == 65536 and len(text) > 250_000_000
+    om = oracle_models("tokenizer_en.matok")
+    res, tot = run_batch(gpu("tokenizer_en.matok"), text, off)
+    assert tot["n_flagged"] == 0 and tot["n_docs"] == 65536 and tot["n_texts"] == 65536
+    counts = om.count_batch(text, off, os.cpu_count() or 1)
+    assert tot["n_tokens"] == int(counts[:, 0].sum())
+    _check_size_independent(res, off, counts)
+    lens = np.diff(off.astype(np.int64))
+    longest = np.flatnonzero(lens == lens.max())
+    rng = np.random.default_rng(3)
+    sample = sorted(set(longest[:64].tolist()) | set(rng.choice(65536, size=2048, replace=False).tolist()))
+    assert len(sample) >= 2048 and lens.max() == 65536
+    assert assert_batch_equals_oracle(om, res, text, off, docs=sample) == len(sample)
+
+
+def test_config5_one_shard_of_the_10gib_corpus(gpu, oracle_models):
+    """BASELINE.json configs[4] as one GPU sees it: 10 GiB = 2 621 440 documents x 4 KiB sharded 8 ways =
+    327 680 documents (1.25 GiB) per GPU; rank 0's shard (seed 5000 + rank, what bench.py --gpus 8 walks).
+    Per-document counts of all 327 680 documents against the oracle's counting pass, the size-independent
+    properties, and every offset of a sample of documents against the oracle."""
+    import datok_amd
+    from datok_amd import corpus
+    n_docs = 327680
+    text, off = corpus.german_docs_sharded(n_docs, 4096, seed=5000)
+    assert len(text) == n_docs * 4096
+    om, tok = oracle_models("tokenizer_de.matok"), gpu("tokenizer_de.matok")
+    with datok_amd.Batch(len(text), n_docs) as b:
+        b.set_input(text, off)
+        b.run(tok, datok_amd.host.OFFSETS_ONLY)
+        tot = b.totals()
+        assert tot["n_flagged"] == 0 and tot["n_docs"] == n_docs and tot["n_texts"] == n_docs
+        res = b.result()
+    counts = om.count_batch(text, off, os.cpu_count() or 1)
+    assert tot["n_tokens"] == int(counts[:, 0].sum()) and tot["n_tokens"] > 150_000_000
+    _check_size_independent(res, off, counts)
+    rng = np.random.default_rng(5)
+    sample = sorted(set(range(64)) | set(range(n_docs - 64, n_docs)) | set(rng.choice(n_docs, size=1024, replace=False).tolist()))
+    assert assert_batch_equals_oracle(om, res, text, off, docs=sample) == len(sample)
 
 
 def _edge_docs():
@@ -198,13 +268,10 @@ def test_edge_documents(gpu, oracle_models, model, flags, chunk, warm):
     docs = _edge_docs()
     text, off = corpus.concat_docs(docs)
     res, tot = run_batch(gpu(model), text, off, flags, chunk=chunk, warm=warm)
-    # the double array may revisit an EOT (datok.go:1019-1030 keeps its window): such
-    # documents are flagged IRREGULAR and excluded, everything else must be bit exact
-    irregular = [d for d in range(len(docs)) if res.status[d] & ST_IRREGULAR]
-    if model.endswith(".matok"):
-        assert not irregular
-    keep = [d for d in range(len(docs)) if d not in set(irregular)]
-    n = assert_batch_equals_oracle(oracle_models(model), res, text, off, flags, docs=keep)
+    # every document, both encodings: calls that are not in position order (the double array revisiting an
+    # EOT, datok.go:1019-1030) are handled by the exact pass and never reported as a status
+    assert not any(int(s) & ST_IRREGULAR for s in res.status)
+    n = assert_batch_equals_oracle(oracle_models(model), res, text, off, flags)
     assert n > 200
 
 
@@ -261,7 +328,7 @@ def test_device_rendering_edge_documents(gpu, oracle_models, model):
     document d (token_writer.go:36-175), for all 16 writer modes x NEWLINE_AFTER_EOT, on the edge
     documents (EOT texts, invalid UTF-8, empty documents, window overflows excluded by status)."""
     import datok_amd
-    from datok_amd import corpus, ST_IRREGULAR
+    from datok_amd import corpus
     docs = _edge_docs()
     text, off = corpus.concat_docs(docs)
     om = oracle_models(model)
@@ -514,17 +581,15 @@ def test_long_documents_with_eot_texts_in_segments(gpu, oracle_models, model, fl
 def test_double_array_long_documents(gpu, oracle_models):
     """The double array's long documents: in segments when they hold no EOT, sequentially otherwise
     (datok.go:1019-1030 keeps the window over an EOT, so the segment carries are not closed-form)."""
-    from datok_amd import corpus, ST_IRREGULAR
+    from datok_amd import corpus
     text, off = corpus.german_docs(6, 60000, seed=41)
     raw = bytearray(text.tobytes())
     for p in (70000, 70001, 130000, 200000):     # documents 1, 2 and 3 get EOTs; 0, 4, 5 stay clean
         raw[p] = 4
     text = np.frombuffer(bytes(raw), dtype=np.uint8)
     res, tot = run_batch(gpu("tokenizer_de.datok"), text, off, NEWLINE_AFTER_EOT, chunk=128)
-    assert tot["n_lanes"] > 64 * 6
-    keep = [d for d in range(6) if not (res.status[d] & ST_IRREGULAR)]
-    assert set(keep) >= {0, 4, 5}
-    assert_batch_equals_oracle(oracle_models("tokenizer_de.datok"), res, text, off, NEWLINE_AFTER_EOT, docs=keep)
+    assert tot["n_lanes"] > 64 * 6 and tot["n_flagged"] == 0
+    assert_batch_equals_oracle(oracle_models("tokenizer_de.datok"), res, text, off, NEWLINE_AFTER_EOT)
     a, _ = run_batch(gpu("tokenizer_de.matok"), text, off, NEWLINE_AFTER_EOT, chunk=128)
     for d in (0, 4, 5):   # without EOT both encodings give the same offsets
         assert np.array_equal(a.doc(d)["tok_rstart"], res.doc(d)["tok_rstart"])
@@ -550,9 +615,8 @@ for name, (text, off) in (("tokenizer_de.matok", corpus.german_docs(96, 4096, se
                 b.set_chunking(chunk, warm)
             b.set_input(text, off); b.run(tok, 0)
             res = b.result()
-            keep = [d for d in range(len(off) - 1) if not (res.status[d] & datok_amd.ST_IRREGULAR)]
-            assert len(keep) > (len(off) - 1) // 2
-            assert_batch_equals_oracle(om, res, text, off, docs=keep)
+            assert not res.status.any()
+            assert_batch_equals_oracle(om, res, text, off)
 print("VARIANT OK")
 """
 
