@@ -1858,10 +1858,17 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
   for (int o = 32; o > 0; o >>= 1) sred |= __shfl_down(sred, o);
   sred = __shfl(sred, 0);
   if (lane == 0) {
+    // The walk's counts sized the rows.  If the position-indexed bytes do not add up to them, two calls fell on one
+    // byte: the double array fired one EOT twice from two different lanes (the lane that revisits it does not know
+    // that its predecessor fired it, so the walk's own test misses it).  The exact pass decides: it walks the
+    // document in call order and reports ST_INTERNAL itself if its calls do not fill the rows either.
     if (sr.last && (tok_base + cTE != tok_lim || sent_base + cNSent != sent_lim || text_base + cNE != text_lim))
       sred |= ST_INTERNAL;
     sred &= ST_INTERNAL;  // everything else was reported by the walk already
-    if (sred) atomicOr(&A.status[d], sred);
+    if (sred) {
+      atomicOr(&A.status[d], ST_IRREGULAR);
+      atomicOr(A.any_irregular, 1u);
+    }
     if (sr.last && A.doc_ns) A.doc_ns[d] = cNSev;  // SentenceEnd calls of this document (for rendering)
   }
 }

@@ -114,9 +114,8 @@ for seed in range(first, first + n_seeds):
             b.set_input(text, off)
             b.run(tok, flags)
             res, tot = b.result(), b.totals()
-            irregular = {d for d in range(len(off) - 1) if res.status[d] & datok_amd.ST_IRREGULAR}
-            assert not irregular or name.endswith(".datok"), (seed, name)
-            keep = [d for d in range(len(off) - 1) if d not in irregular]
+            assert not any(int(x) & datok_amd.ST_IRREGULAR for x in res.status), (seed, name)  # the exact pass took them
+            keep = list(range(len(off) - 1))
             try:
                 assert_batch_equals_oracle(om, res, text, off, flags, docs=keep)
             except AssertionError:  # keep the failing batch for a closer look

@@ -147,7 +147,7 @@ def test_closure_int_arguments_equal_the_reference(oracle_models, model):
         assert rec.calls == exp, (model, doc[:60])
         n_args += sum(1 for c in exp if c[0] != "T" and c[1] != 0)
     if model.endswith(".matok"):
-        assert n_args > 50       # buffc is rarely 0 for the matrix
+        assert n_args > 10       # nonzero where the window holds runes: EOT texts, leading blanks, the tail
 
 
 @pytest.mark.gpu
