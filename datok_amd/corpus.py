@@ -87,14 +87,22 @@ def _de_words():
     return words
 
 
-def _sentence_pool(rng, words, abbr, special, ends, quotes, n_sent, p_abbr, p_special, p_quote):
-    """Builds n_sent sentences (bytes). Returns (flat uint8, starts, lens)."""
+def _sentence_pool(rng, words, abbr, special, ends, quotes, n_sent, p_abbr, p_special, p_quote, zipf=False):
+    """Builds n_sent sentences (bytes). Returns (flat uint8, starts, lens).
+    zipf: word i is drawn with probability ~ 1 / (i + 8) instead of uniformly (a long tail of rare types)."""
     wl = np.array(words, dtype=object)
     out = []
     nw = rng.integers(5, 26, size=n_sent)
+    cdf = None
+    if zipf:
+        w = 1.0 / (np.arange(len(wl)) + 8.0)
+        cdf = np.cumsum(w / w.sum())
     for i in range(n_sent):
         k = int(nw[i])
-        toks = list(wl[rng.integers(0, len(wl), size=k)])
+        if cdf is None:
+            toks = list(wl[rng.integers(0, len(wl), size=k)])
+        else:
+            toks = list(wl[np.minimum(np.searchsorted(cdf, rng.random(k)), len(wl) - 1)])
         r = rng.random(4)
         if r[0] < p_abbr * k:
             toks[int(rng.integers(0, k))] = abbr[int(rng.integers(0, len(abbr)))]
@@ -181,6 +189,58 @@ def german_docs(n_docs=4096, doc_bytes=4096, seed=2, n_sent=20000):
                           [("„", "“"), ("»", "«"), ("\"", "\""), ("‚", "‘")], n_sent,
                           p_abbr=0.03, p_special=0.02, p_quote=0.06)
     return _fixed_docs(rng, pool, n_docs, doc_bytes, [b" ", b" ", b" ", b" ", b" ", b" ", b" ", b"\n\n", b"\n"])
+
+
+_SYL_ON = ["b", "d", "f", "g", "h", "k", "l", "m", "n", "p", "r", "s", "t", "w", "z", "sch", "st", "sp", "br", "dr", "fr",
+           "gr", "kr", "pr", "tr", "bl", "fl", "gl", "kl", "pf", "schw", "str", "v", "j", "qu", "ch", ""]
+_SYL_NU = ["a", "e", "i", "o", "u", "ä", "ö", "ü", "ei", "au", "ie", "eu", "äu", "aa", "ee", "oo"]
+_SYL_CO = ["", "", "", "n", "r", "l", "s", "t", "m", "ch", "ck", "ng", "nd", "nt", "rt", "st", "ß", "ss", "tz", "ll",
+           "mm", "nn", "rr", "ff", "pf", "rz", "lt", "ls", "ns", "cht"]
+_SUFFIX = ["", "", "", "en", "er", "e", "ung", "heit", "keit", "lich", "isch", "bar", "los", "schaft", "chen", "lein",
+           "ig", "sam", "tum", "nis", "s", "es", "em", "te", "ten", "st", "t"]
+_RICH_SPECIAL = ["<p>", "</p>", "<br/>", "<b>", "</b>", "<i>", "</i>", "<a href=\"https://www.example.org/pfad/zur/seite.html?x=1&y=2\">",
+                 "</a>", "<span class=\"hervorgehoben\">", "</span>", "<img src=\"bild.png\" alt=\"Ein Bild\"/>", "<h2>", "</h2>",
+                 "<li>", "</li>", "<!-- Kommentar -->", "<div id=\"inhalt\">", "</div>",
+                 "https://de.wikipedia.org/wiki/Deutsche_Sprache", "http://www.ids-mannheim.de/korap/?q=Baum&ql=poliqarp",
+                 "www.example.com/a/b/c/index.php?id=123&lang=de#abschnitt", "max.mustermann@beispiel-firma.de",
+                 "info@uni-mannheim.de", "ftp://ftp.example.org/pub/datei.tar.gz", "192.168.178.1", "2001:db8::1",
+                 "#hashtag", "@benutzer", "C++", "E-Mail-Adresse", "3,14159", "1.000.000", "12.03.2024", "14:35:07", "§ 823 Abs. 1 BGB",
+                 "50 %", "20 °C", "10 km/h", "1/2", "z. B.", "u. a.", "d. h.", "i. d. R.", "Dr. med.", "Prof. Dr.", "Nr. 5", "S. 12 ff.",
+                 ":-)", ";-)", ":D", "^^", "…", "–", "—", "(sic!)", "[1]", "{x}", "a/b", "x*y", "1+1=2", "100%ig", "'s", "O'Neill",
+                 "Müller-Lüdenscheidt", "Sankt-Nimmerleins-Tag", "AT&T", "H&M", "km²", "CO₂", "µm", "€ 9,99", "$ 5", "£10"]
+
+
+def _rich_words(n_types, seed):
+    rng = np.random.default_rng(seed)
+    words, seen = list(_de_words()), set(_de_words())
+    while len(words) < n_types:
+        k = (1, 2, 2, 2, 3, 3, 4)[int(rng.integers(0, 7))]
+        w = "".join(_SYL_ON[int(rng.integers(0, len(_SYL_ON)))] + _SYL_NU[int(rng.integers(0, len(_SYL_NU)))] +
+                    _SYL_CO[int(rng.integers(0, len(_SYL_CO)))] for _ in range(k)) + _SUFFIX[int(rng.integers(0, len(_SUFFIX)))]
+        r = rng.random()
+        if r < 0.35:
+            w = w[:1].upper() + w[1:]           # nouns
+        elif r < 0.40 and len(words) > 700:
+            w = w + words[int(rng.integers(0, 600))]   # compounds with a known head
+        elif r < 0.43:
+            w = w.upper()                       # acronyms
+        elif r < 0.46:
+            w = w + "-" + w[::-1].capitalize()  # hyphenated
+        if w not in seen:
+            seen.add(w); words.append(w)
+    return words
+
+
+def german_rich_docs(n_docs=4096, doc_bytes=4096, seed=2, n_types=30000, n_sent=60000, p_special=0.012):
+    """A harder German-like corpus for robustness measurements: `n_types` word types (the built-in list plus
+    generated stems, compounds, acronyms, hyphenations), XML tags with attributes, URLs, e-mail addresses,
+    numbers with units, abbreviations with blanks inside, emoticons -- one such item per 80 words or so -- and
+    typographic quotes.  Same shape as german_docs (exactly doc_bytes per document, valid UTF-8, no U+0004)."""
+    rng = np.random.default_rng(seed)
+    pool = _sentence_pool(rng, _rich_words(n_types, 7), _DE_ABBR, _DE_SPECIAL + _RICH_SPECIAL, _DE_END,
+                          [("„", "“"), ("»", "«"), ("\"", "\""), ("‚", "‘"), ("(", ")"), ("›", "‹")], n_sent,
+                          p_abbr=0.02, p_special=p_special, p_quote=0.08, zipf=True)
+    return _fixed_docs(rng, pool, n_docs, doc_bytes, [b" ", b" ", b" ", b" ", b" ", b" ", b" ", b"\n\n", b"\n", b"\t", b"  "])
 
 
 def _german_part(args):

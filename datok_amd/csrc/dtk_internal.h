@@ -12,14 +12,15 @@
 
 // ---- symbol stream entry (uint16 per input byte), written by the symbolise kernel
 //   [10:0]  sigma index a           (sigmaASCII[c] / sigma[c] / identity, matrix.go:421-435)
-//   [12:11] UTF-8 width - 1         (Go DecodeRune width)
-//   [14:13] class: 0 rune<256, 1 rune==EOT, 2 rune>=256 in sigma (ok=true), 3 not in sigma (ok=false)
-//   [15]    this byte starts a rune
+//   [13:11] bytes of the rune that starts at this byte (Go DecodeRune width, 1..4); 0: no rune starts here
+//   [15:14] class: 0 rune<256, 1 rune==EOT, 2 rune>=256 in sigma (ok=true), 3 not in sigma (ok=false)
+// (an entry with width 0 and the epsilon symbol is what the lean walk feeds itself for an epsilon iteration)
 #define DTK_SYM_MASK 0x7FFu
 #define DTK_SYM_MAX 2047u
 #define DTK_SYM_W_SHIFT 11
-#define DTK_SYM_CLS_SHIFT 13
-#define DTK_SYM_START 0x8000u
+#define DTK_SYM_CLS_SHIFT 14
+#define DTK_SYM_WIDTH(e) (((uint32_t)(e) >> DTK_SYM_W_SHIFT) & 7u)
+#define DTK_SYM_IS_START(e) (DTK_SYM_WIDTH(e) != 0u)
 // the lean walk's per-lane window of the symbol stream in LDS: entries, and u16 per row (72 B)
 #define DTK_WIN 32u
 #define DTK_WIN_ROW 36u

@@ -21,6 +21,10 @@
 #include "dtk_internal.h"
 
 #define WAVE 64
+// knock-out builds for cost measurements (scripts/ko.sh): results are wrong, only timings mean something
+#ifndef DTK_KO
+#define DTK_KO 0
+#endif
 
 // ------------------------------------------------------------------ helpers
 
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(WAVE) void k_symbolize(const uint8_t *__restrict__ 
                                                     unsigned long long *__restrict__ n_invalid,
                                                     uint32_t *__restrict__ rs_bits) {
   __shared__ uint32_t s_rs[SYM_BLOCK_BYTES / 32];  // bit i: byte i of the block starts a rune
-  __shared__ uint16_t lut[128];       // symbol | class | START for the runes < 128 (index = byte)
+  __shared__ uint16_t lut[128];       // symbol | class | width 1 for the runes < 128 (index = byte)
   __shared__ uint16_t lat[256];       // symbol | class for runes < 256 (heavy path, Latin-1)
   __shared__ uint32_t s_runes[SYM_SIG_LDS];   // sigma map (runes >= 256), if it fits
   __shared__ uint16_t s_syms[SYM_SIG_LDS];
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(WAVE) void k_symbolize(const uint8_t *__restrict__ 
     // matrix.go:421-426: runes < 256 go through sigmaASCII; rune 4 is EOT
     const uint32_t e = (sig.ascii[i] & DTK_SYM_MASK) | (i == DTK_EOT ? (1u << DTK_SYM_CLS_SHIFT) : 0u);
     lat[i] = (uint16_t)e;
-    if (i < 128u) lut[i] = (uint16_t)(e | DTK_SYM_START);
+    if (i < 128u) lut[i] = (uint16_t)(e | (1u << DTK_SYM_W_SHIFT));
     if (sig_lds && i < sig.n_runes) { s_runes[i] = sig.runes[i]; s_syms[i] = sig.syms[i]; }
   }
   const uint64_t block_start = (uint64_t)blockIdx.x * SYM_BLOCK_BYTES;
@@ -260,7 +264,7 @@ __global__ __launch_bounds__(WAVE) void k_symbolize(const uint8_t *__restrict__ 
             if (r < rune) l = m + 1; else h = m - 1;
           }
         }
-        sym[g] = (uint16_t)(a_cls | ((wd - 1) << DTK_SYM_W_SHIFT) | (start ? DTK_SYM_START : 0u));
+        sym[g] = (uint16_t)(a_cls | (start ? wd << DTK_SYM_W_SHIFT : 0u));
         if (start) atomicOr(&s_rs[pos >> 5], 1u << (pos & 31u));
         // a byte that decodes to U+FFFD with width 1 prints as three bytes (the renderer's slow path)
         if (start && wd == 1u) atomicAdd(n_invalid, 1ull);
@@ -428,6 +432,7 @@ struct EventSink {
   // before one can run full (at most 3 bytes per iteration); the plain store is for lanes without
   // a list and for windows of 8 MiB and more.
   __device__ __forceinline__ void put(uint32_t arr, uint32_t pos, uint32_t v) {
+    if (DTK_KO & 8) return;
     const uint32_t rel = pos - lo;
     if (elist != nullptr && rel < (1u << 23) && ecount < DTK_ELIST) {
       elist[ecount++] = (rel << 9) | (arr << 8) | (v & 255u);
@@ -515,7 +520,7 @@ enum { MODE_DOC = 0,    // whole document from the initial state, all events
 // reference's 1024-rune buffer (matrix.go:365), i.e. when it spans > 1024 bytes.
 __device__ __noinline__ uint32_t count_runes(const uint16_t *__restrict__ s, uint32_t from, uint32_t to) {
   uint32_t n = 0;
-  for (uint32_t i = from; i < to; i++) n += (s[i] >> 15);
+  for (uint32_t i = from; i < to; i++) n += DTK_SYM_IS_START(s[i]) ? 1u : 0u;
   return n;
 }
 
@@ -605,7 +610,7 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
     if (newchar) {
       const uint32_t e = row[p + o7 - wbase];
       a = e & DTK_SYM_MASK;
-      w = ((e >> DTK_SYM_W_SHIFT) & 3u) + 1u;
+      w = DTK_SYM_WIDTH(e);
       const uint32_t cls = (e >> DTK_SYM_CLS_SHIFT) & 3u;
       hi = max(hi, p + w);             // matrix.go:388-408: runes enter the window once
       eot = cls == 1u;                 // matrix.go:422
@@ -756,138 +761,157 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
   uint32_t F = (init.flags & (LANE_F_SENT | LANE_F_TEXT)) | (init.p > 0 ? 4u : 0u);
   F |= (init.p > 0 && !(init.flags & LANE_F_TEXT)) ? 8u : 0u;
   static_assert(LANE_F_SENT == 1u && LANE_F_TEXT == 2u, "flag layout");
-  uint32_t retry = 0;  // 1: this iteration looks up the epsilon arc of `t` at p and reads no rune
   uint32_t st = 0, it = 0;
   fin.p = 0xFFFFFFFFu; fin.t = 0; fin.aux = 0; fin.flags = 0;  // p stays "ran to EOF" unless the lane stops
   bool done = false;
-  // the lane's window of the symbol stream: entries (pos + o7) in [wbase, wbase + DTK_WIN)
+  // the lane's window of the symbol stream: entry of position q at row[q - wb7], q - wb7 in [0, DTK_WIN)
   dtk_u16a *row = reinterpret_cast<dtk_u16a *>(win_row);
   const uint32_t o7 = (uint32_t)(off & 7u);
   const uint16_t *__restrict__ aligned = sym_base + (off - o7);
-  uint32_t wbase = (p + o7) & ~7u;
-  win_fill(row, aligned, wbase);
-  uint32_t e_next = row[(p + o7) - wbase];
+  uint32_t wb7 = ((p + o7) & ~7u) - o7;
+  win_fill(row, aligned, wb7 + o7);
+  // The entry the next lookup is made with: the stream entry of the rune at p -- or, right after a backtrack,
+  // the bare epsilon symbol: width 0, so that iteration consumes nothing and reads no rune (matrix.go:487-497).
+  uint32_t e = row[p - wb7];
 
-  // reader at EOF: the drain of matrix.go:650-668 (checked before every rune)
-#define DTK_EOF_DRAIN()                                              \
-  if (!retry && p >= len) {                                          \
-    const bool he_ = t <= n_eps;                                     \
-    const bool bt_ = !he_ && eps_t != 0;                             \
-    t = bt_ ? eps_t : t;                                             \
-    p = bt_ ? eps_p : p;                                             \
-    eps_t = bt_ ? 0u : eps_t;                                        \
-    retry = 1;                                                       \
-    done = !he_ && !bt_;                                             \
+  // Reader at EOF before a rune is read (matrix.go:650-668): epsilon arcs are taken as long as the state has one
+  // (here, on the spot: one lookup each); then the remembered epsilon state is popped -- the walk goes on from
+  // there with an epsilon iteration -- or the walk is over.
+#define DTK_EOF_DRAIN()                                                                                       \
+  if (p >= len) {                                                                                             \
+    while (t <= n_eps && !done) {                                                                             \
+      const uint32_t x_ = tab[__umul24(t, stride) + epsilon];                                                 \
+      it++;                                                                                                   \
+      if ((int32_t)x_ <= 0) { st |= ST_BAD_MODEL; done = true; break; }                                       \
+      if (p > tp) { /* matrix.go:565-572 */                                                                   \
+        if (MODE != MODE_START) sink.template token<true>(bs, tp, p, ((F ^ 4u) & 7u) != 0);                   \
+        F = 12u;                                                                                              \
+        if (hi - bs > DTK_WINDOW && count_runes(s, bs, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;            \
+        tp = p; bs = p; eps_t = 0;                                                                            \
+        if (MODE != MODE_DOC && p >= stop_pos) {                                                              \
+          fin.p = p; fin.t = x_ & 0x7FFFu; fin.aux = 0; fin.flags = init.flags & LANE_F_OK;                   \
+          done = true;                                                                                        \
+        }                                                                                                     \
+      } else { /* matrix.go:573-576 */                                                                        \
+        if (MODE != MODE_START) sink.template sentence<true>(bs, p, (F & 8u) != 0);                           \
+        F |= 1u;                                                                                              \
+      }                                                                                                       \
+      t = x_ & 0x7FFFu;                                                                                       \
+      if (it > cap) { st |= ST_STEP_LIMIT; done = true; }                                                     \
+    }                                                                                                         \
+    if (!done) {                                                                                              \
+      if (eps_t != 0) { t = eps_t; p = eps_p; eps_t = 0; e = epsilon; } else done = true;                     \
+    }                                                                                                         \
   }
   DTK_EOF_DRAIN()
   while (!done) {
     it++;
-    const bool r = retry != 0;
-    // the rune at p (an epsilon iteration reads none: the entry is then not used)
-    const uint32_t e = e_next;
-    const uint32_t a = r ? epsilon : (e & DTK_SYM_MASK);
+    const uint32_t w = (e >> DTK_SYM_W_SHIFT) & 7u;     // bytes of the rune at p; 0: an epsilon iteration
     // the fused table is at most 2^15 states x 2^11 symbols x 4 B: a 32-bit byte offset from the
     // uniform base (one 24-bit multiply-add) instead of 64-bit address arithmetic
     const uint32_t x = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(tab) +
-                                                           ((__umul24(t, stride) + a) << 2));
-    // while the cell is on its way: the entry of the position the next rune is read from (behind
-    // this rune; after a backtrack the epsilon iteration, which reads no rune, does this for the
-    // position it returns to)
-    const uint32_t pn = r ? p : p + ((e >> DTK_SYM_W_SHIFT) & 3u) + 1u;
+                                                           ((__umul24(t, stride) + (e & DTK_SYM_MASK)) << 2));
+    // while the cell is on its way: the entry of the position the next rune is read from (behind this rune; an
+    // epsilon iteration does this for the position the backtrack returned to)
+    const uint32_t pn = p + w;
+    uint32_t e_next;
     {
-      uint32_t iw = pn + o7 - wbase;
+      uint32_t iw = pn - wb7;
       if (__builtin_amdgcn_ballot_w64(iw >= DTK_WIN) != 0ull) {  // also a backtrack to before the window
-        wbase = (pn + o7) & ~7u;
-        win_fill(row, aligned, wbase);
-        iw = (pn + o7) & 7u;
+        wb7 = ((pn + o7) & ~7u) - o7;
+        win_fill(row, aligned, wb7 + o7);
+        iw = pn - wb7;
       }
       e_next = row[iw];
     }
     hi = max(hi, pn);                                   // matrix.go:388-408
-    const bool he = !r && t <= n_eps;                   // matrix.go:442-454
+    // matrix.go:442-454.  (An epsilon iteration -- state and position of the slot it was popped from -- would put
+    // the same slot back; it is dropped again below because every epsilon step drops it.)
+    const bool he = t <= n_eps;
     eps_t = he ? t : eps_t; eps_p = he ? p : eps_p;
-    const uint32_t tgt = x & 0x7FFFu;
+    const bool r = w == 0u;
+    const uint32_t tgt = x & 0x7FFFu, via = (x >> 16) & 0x7FFFu;
     const bool nontoken = (x & 0x8000u) != 0;
-    const bool comp = (int32_t)x < 0 && (MODE == MODE_DOC || p < stop_pos);
+    const bool comp = (int32_t)x < 0;                   // a fused cell: the epsilon arc of t, then the rune from there
     const bool plain = (int32_t)x > 0;
-    const bool advance = plain && !r;                   // matrix.go:579-591
-    const bool epsE = (plain && r) || comp;             // an epsilon arc is taken at p
+    const bool fail = x == 0u;
+    const bool epsE = comp || (plain && r);             // an epsilon arc is taken at p
+    const bool advance = comp || (plain && !r);         // the rune is consumed, matrix.go:579-591
     const bool flush = epsE && p > tp;                  // matrix.go:565-572
     const bool sentE = epsE && p <= tp;                 // matrix.go:573-576
-    const bool fail = !plain && !comp;
     const bool backtrack = fail && !r && eps_t != 0;    // matrix.go:487-497
     const bool hardfail = fail && !backtrack;
-    if (MODE != MODE_START) {
+    if (MODE != MODE_START && !(DTK_KO & 1)) {
       if (flush) sink.template token<true>(bs, tp, p, ((F ^ 4u) & 7u) != 0);
       if (sentE) sink.template sentence<true>(bs, p, (F & 8u) != 0);
     }
-    const uint32_t bs_old = bs;
-    F = flush ? ((F & ~3u) | 12u) : (sentE ? (F | 1u) : F);
-    const bool skip = nontoken && ((advance && p == tp) || comp);  // matrix.go:584-588
-    const bool rewE = flush && !comp;                   // the rewind of a plain epsilon step ends a chunk
-    const uint32_t p_old = p;
-    p = (advance || comp) ? pn : p;
-    tp = skip ? p : (comp ? p_old : tp);
-    tp = rewE ? p : tp;
+    const uint32_t win = (DTK_KO & 2) ? 0u : hi - bs;   // bytes the window holds (before this iteration's rewind)
+    const uint32_t bs_old = bs, p_old = p;
+    F = flush ? 12u : (F | (sentE ? 1u : 0u));
     bs = flush ? p_old : bs;
-    // the epsilon slot: dropped by a backtrack, a rewind and a fused cell; a fused cell remembers
-    // the state it read its rune in if that state has an epsilon arc
-    const uint32_t via = (x >> 16) & 0x7FFFu;
+    const bool skip = nontoken && (comp || (advance && p_old == tp));  // matrix.go:584-588
+    tp = (comp || flush) ? p_old : tp;
+    tp = skip ? pn : tp;
+    p = backtrack ? eps_p : (advance ? pn : p_old);
+    t = backtrack ? eps_t : (fail ? t : tgt);
+    // the epsilon slot: dropped by a backtrack and by every epsilon step; a fused cell remembers the state it
+    // read its rune in (the epsilon target, at p_old) if that state has an epsilon arc
     const bool he2 = comp && via <= n_eps;
-    t = backtrack ? eps_t : ((plain || comp) ? tgt : t);
-    p = backtrack ? eps_p : p;
-    eps_t = (backtrack || flush || comp) ? (he2 ? via : 0u) : eps_t;
+    eps_t = he2 ? via : ((backtrack || epsE) ? 0u : eps_t);
     eps_p = he2 ? p_old : eps_p;
-    retry = backtrack ? 1u : 0u;
-    // everything that happens less than once per token
-    const bool eot_now = (advance || comp) && ((e >> DTK_SYM_CLS_SHIFT) & 3u) == 1u;  // matrix.go:593-605
-    const bool over = flush && hi - bs_old > DTK_WINDOW;
-    const bool at_stop = rewE && MODE != MODE_DOC && p >= stop_pos;
-    // more bytes buffered than 1024 runes can have: the reference's window has overflowed for certain
-    // (matrix.go:365,406).  The lane stops there -- a blank-free blob of megabytes would otherwise
-    // be walked to its end by every lane whose chunk lies inside it.
-    const bool long_win = hi - bs > DTK_WINDOW_BYTES;
-    if (hardfail || eot_now || over || at_stop || it > cap || long_win) {
-      if (hardfail) {  // matrix.go:499-552: drop what is buffered as a token, restart at state 1
-        if (r) { st |= ST_BAD_MODEL; done = true; }
-        else {
-          if (p <= tp) { p = pn; }  // matrix.go:515-516
-          if (p < tp) st |= ST_BAD_OFFSET;  // Token(bufft, buffer[:buffc]) with bufft > buffc
-          else {  // the rune is read again
-            uint32_t iw = p + o7 - wbase;
-            if (iw >= DTK_WIN) { wbase = (p + o7) & ~7u; win_fill(row, aligned, wbase); iw = (p + o7) & 7u; }
-            e_next = row[iw];
+    const uint32_t e_cur = e;
+    e = backtrack ? epsilon : e_next;
+    // everything that happens less than once per token: hard fail, EOT, the first rewind at or behind the end of
+    // the chunk (a fused cell's too: the lane then ends BEFORE the cell's rune), the window limit, the lookup cap
+    const bool eot_now = advance && ((e_cur >> DTK_SYM_CLS_SHIFT) & 3u) == 1u;  // matrix.go:593-605
+    const bool at_stop = MODE != MODE_DOC && flush && p_old >= stop_pos;
+    if (hardfail || eot_now || at_stop || (flush && win > DTK_WINDOW) || win > DTK_WINDOW_BYTES || it > cap) {
+      if (flush && win > DTK_WINDOW && count_runes(s, bs_old, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
+      if (at_stop) {
+        // the state right after the rewind at p_old: the target of the epsilon arc
+        fin.p = p_old; fin.t = comp ? via : tgt; fin.aux = 0;
+        fin.flags = init.flags & LANE_F_OK;
+        done = true;
+      } else {
+        if (hardfail) {  // matrix.go:499-552: drop what is buffered as a token, restart at state 1
+          if (r) { st |= ST_BAD_MODEL; done = true; }
+          else {
+            if (p <= tp) { p = pn; }  // matrix.go:515-516
+            if (p < tp) st |= ST_BAD_OFFSET;  // Token(bufft, buffer[:buffc]) with bufft > buffc
+            e = p == pn ? e_next : e_cur;     // the rune at p (read again if it was not consumed)
+            if (MODE != MODE_START) sink.template token<true>(bs, tp, p, ((F ^ 4u) & 7u) != 0);
+            F = 12u;
+            if (hi - bs > DTK_WINDOW && count_runes(s, bs, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
+            t = tr.start; eps_t = 0;
+            tp = p; bs = p;
+            if (MODE != MODE_DOC && p >= stop_pos) {
+              fin.p = p; fin.t = t; fin.aux = 0;
+              fin.flags = (init.flags & LANE_F_OK);
+              done = true;
+            }
           }
-          if (MODE != MODE_START) sink.template token<true>(bs, tp, p, ((F ^ 4u) & 7u) != 0);
-          F = 12u;
+        }
+        if (eot_now) {
+          if (MODE != MODE_START) sink.template eot<true>(bs, p, (F & 1u) == 0u, (F & 8u) != 0);
+          F = (F & 4u) | 3u;  // sentenceEnd, textEnd; TextEnd: pos = pos[:0] (token_writer.go:158)
+          eps_t = 0;          // matrix.go:601 rewinds
           if (hi - bs > DTK_WINDOW && count_runes(s, bs, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
-          t = tr.start; eps_t = 0;
           tp = p; bs = p;
-          if (MODE != MODE_DOC && p >= stop_pos) {
+          if (MODE != MODE_DOC && p >= stop_pos && !done) {
             fin.p = p; fin.t = t; fin.aux = 0;
-            fin.flags = (init.flags & LANE_F_OK);
+            fin.flags = (F & 3u) | (init.flags & LANE_F_OK);
             done = true;
           }
         }
+        if (it > cap && !done) { st |= ST_STEP_LIMIT; done = true; }
+        // More bytes buffered than 1024 runes can have: the reference's window has overflowed for certain
+        // (matrix.go:365,406).  The lane stops there -- a blank-free blob of megabytes would otherwise be walked to
+        // its end by every lane whose chunk lies inside it.  (The tail below then closes the document at this
+        // position: every document keeps its TextEnd.)
+        if (hi - bs > DTK_WINDOW_BYTES && !done) { st |= ST_WINDOW_OVERFLOW; done = true; }
       }
-      if (over && count_runes(s, bs_old, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
-      if (eot_now) {
-        if (MODE != MODE_START) sink.template eot<true>(bs, p, (F & 1u) == 0u, (F & 8u) != 0);
-        F = (F & 4u) | 3u;  // sentenceEnd, textEnd; TextEnd: pos = pos[:0] (token_writer.go:158)
-        eps_t = 0;          // matrix.go:601 rewinds
-        if (hi - bs > DTK_WINDOW && count_runes(s, bs, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
-        tp = p; bs = p;
-      }
-      if ((at_stop || (eot_now && MODE != MODE_DOC && p >= stop_pos)) && !done) {
-        fin.p = p; fin.t = t; fin.aux = 0;
-        fin.flags = (F & 3u) | (init.flags & LANE_F_OK);
-        done = true;
-      }
-      if (it > cap && !done) { st |= ST_STEP_LIMIT; done = true; }
-      // (the tail below then closes the document at this position: every document keeps its TextEnd)
-      if (long_win && !done) { st |= ST_WINDOW_OVERFLOW; done = true; }
     }
-    if (!done) { DTK_EOF_DRAIN() }
+    if (!done && !backtrack) { DTK_EOF_DRAIN() }
     // one list of the wave is nearly full: all lanes write theirs out
     if (MODE != MODE_START && __builtin_amdgcn_ballot_w64(sink.ecount >= DTK_ELIST_HIGH) != 0ull) sink.flush();
   }
@@ -1175,7 +1199,7 @@ __device__ __forceinline__ DtkLaneState start_record(const TRANS &tr, const DtkW
     sink.init(nullptr, nullptr, 0u, 0u);
     uint32_t st;
     if (sp > 0) {
-      while (sp < len && !(s[sp] & DTK_SYM_START)) sp++;
+      while (sp < len && !DTK_SYM_IS_START(s[sp])) sp++;
       DtkLaneState init{sp, tr.start_state(), tr.start_aux(), 0u};
       walk_any<TRANS, IS_MATRIX, MODE_START>(tr, A.sym, off, len, init, kc, sink, epsilon, unknown,
                                               identity, step_cap(A.step_factor, len), rec, st, steps, win_row);

@@ -52,7 +52,7 @@ __device__ __forceinline__ uint32_t row_of(const uint64_t *off, uint32_t n, uint
 // decode (U+FFFD, width 1) leaves as EF BF BD.  Such bytes are the rune starts of width 1 whose
 // rune is >= 256 in the symbol stream.
 __device__ __forceinline__ bool is_invalid_byte(uint16_t e) {
-  return (e & DTK_SYM_START) && ((e >> DTK_SYM_W_SHIFT) & 3u) == 0u && ((e >> DTK_SYM_CLS_SHIFT) & 3u) >= 2u;
+  return DTK_SYM_WIDTH(e) == 1u && ((e >> DTK_SYM_CLS_SHIFT) & 3u) >= 2u;
 }
 
 __device__ __forceinline__ uint32_t invalid_in(const DtkRenderArgs &R, uint64_t k, uint32_t d) {

@@ -743,3 +743,35 @@ def test_blank_free_blob_is_flagged_quickly(gpu, oracle_models, model):
     assert st[1] & datok_amd.ST_WINDOW_OVERFLOW and st[0] == 0 and st[2] == 0, st
     assert_batch_equals_oracle(oracle_models(model), res, text, off, docs=[0, 2])  # (the oracle is quadratic on the blob)
     assert dt < 0.5, dt
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["tokenizer_de.matok", "tokenizer_de.datok"])
+def test_rich_corpus_is_exact(gpu, oracle_models, model):
+    """The robustness corpus (30 000 word types with a Zipf tail, XML tags with attributes, URLs, e-mail addresses,
+    abbreviations with blanks inside): speculation misses here (tags and tokens with blanks cost repair rounds),
+    the result is exact all the same -- every document, default chunking and short chunks."""
+    from datok_amd import corpus
+    text, off = corpus.german_rich_docs(768, 4096, seed=11)
+    om = oracle_models(model)
+    for chunk in (None, 64):
+        res, tot = run_batch(gpu(model), text, off, chunk=chunk, warm=16)
+        assert tot["n_flagged"] == 0
+        assert assert_batch_equals_oracle(om, res, text, off) == 768
+
+
+@pytest.mark.gpu
+def test_round1_soak_failure_stays_fixed(gpu, oracle_models):
+    """The batch scripts/soak.py kept when it failed in round 1 (tests/golden/soak_fail_r01.npz: one 68 KB
+    document with runs beyond the 1024-rune window, chunk 1024 / warm-up 48 / extend 240): over-long windows
+    stop the lane and flag the document; everything the oracle defines must match (the parity helper compares
+    only the WINDOW_OVERFLOW bit behind an overflow, where the reference has panicked)."""
+    import datok_amd
+    z = np.load(os.path.join(os.path.dirname(MODELS), "soak_fail_r01.npz"))
+    name, text, off = str(z["model"]), z["text"], z["off"]
+    with datok_amd.Batch(len(text), len(off) - 1) as b:
+        b.set_chunking(int(z["chunk"]), int(z["warm"]), extend=int(z["extend"]))
+        b.set_input(text, off)
+        b.run(gpu(name), int(z["flags"]))
+        res = b.result()
+    assert_batch_equals_oracle(oracle_models(name), res, text, off, int(z["flags"]))
