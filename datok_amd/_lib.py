@@ -49,7 +49,7 @@ class ResultView(C.Structure):
                 ("tok_rstart", C.c_void_p), ("tok_rend", C.c_void_p),
                 ("tok_bstart", C.c_void_p), ("tok_bend", C.c_void_p),
                 ("sent", C.c_void_p), ("text_tok_end", C.c_void_p), ("text_sent_end", C.c_void_p),
-                ("status", C.c_void_p), ("events", C.c_void_p), ("events_open", C.c_void_p),
+                ("status", C.c_void_p), ("ev_bits", C.c_void_p), ("ev_words", C.c_uint64), ("doc_tail", C.c_void_p),
                 ("n_exact", C.c_uint32), ("exact_doc", C.c_void_p), ("exact_off", C.c_void_p),
                 ("calls", C.c_void_p)]
 

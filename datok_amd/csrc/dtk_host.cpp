@@ -697,8 +697,9 @@ struct dtk_batch {
   // intermediates
   uint16_t *d_sym = nullptr;
   uint32_t *d_rsbits = nullptr;                // rune-start bitmap of the input (1 bit per byte)
-  uint8_t *d_ev = nullptr;                     // both event arrays, cleared by one memset
-  uint8_t *d_evA = nullptr, *d_evB = nullptr;  // closing / opening event bytes (carved per run)
+  uint32_t *d_bits = nullptr;                  // event bitmaps of the walk (EVB_KINDS kinds), cleared every run
+  uint32_t bit_words = 0;                      // words per kind of the current input
+  uint32_t *d_doc_tail = nullptr;              // per document: final SentenceEnd / TextEnd (carved from d_acc)
   uint8_t *d_acc = nullptr;                    // per-document accumulators + totals (one memset)
   uint64_t acc_bytes = 0;
   uint32_t *d_status = nullptr;
@@ -765,7 +766,7 @@ struct dtk_batch {
   std::vector<uint64_t> h_tok_off, h_sent_off, h_text_off;
   std::vector<int32_t> h_rstart, h_rend, h_sent;
   std::vector<uint32_t> h_bstart, h_bend, h_ttok, h_tsent, h_status;
-  std::vector<uint8_t> h_events, h_events_b;
+  std::vector<uint32_t> h_bits, h_doc_tail;
 };
 
 static int alloc_outputs(dtk_batch *b, uint64_t tok, uint64_t sent, uint64_t text) {
@@ -818,8 +819,9 @@ extern "C" int dtk_batch_create(uint64_t max_bytes, uint32_t max_docs, dtk_batch
   B_TRY(hipMalloc((void **)&b->d_sym, (max_bytes + pad) * 2));
   B_TRY(hipMalloc((void **)&b->d_rsbits, (max_bytes + pad) / 8 + 64));
   // per array: total + 4 * n_docs + 4 slots, rounded up to 256 by dtk_batch_run
-  B_TRY(hipMalloc((void **)&b->d_ev, 2 * (max_bytes + 4ull * max_docs + 2 * pad)));
-  b->acc_bytes = 64 + 3 * ((uint64_t)max_docs + 1) * 8 + 3 * (uint64_t)max_docs * 4 + 64;
+  // one bit per cursor position and kind: total + n_docs positions, rounded up to 16 bytes per kind, two words of slack
+  B_TRY(hipMalloc((void **)&b->d_bits, (EVB_KINDS * ((max_bytes + max_docs) / 32 + 8) + 8) * 4));
+  b->acc_bytes = 64 + 3 * ((uint64_t)max_docs + 1) * 8 + 4 * (uint64_t)max_docs * 4 + 64;
   B_TRY(hipMalloc((void **)&b->d_acc, b->acc_bytes));
   B_TRY(hipMalloc((void **)&b->d_redo, (uint64_t)max_docs * 4));
   B_TRY(hipMalloc((void **)&b->d_blk_doc, (max_bytes / DTK_SYM_BLOCK_BYTES + 3) * 4));
@@ -845,7 +847,7 @@ extern "C" int dtk_batch_create(uint64_t max_bytes, uint32_t max_docs, dtk_batch
 extern "C" void dtk_batch_free(dtk_batch *b) {
   if (!b) return;
   if (b->stream) (void)hipStreamSynchronize(b->stream);
-  void *ptrs[] = {b->d_text_own, b->d_off_own, b->d_sym, b->d_rsbits, b->d_ev, b->d_acc, b->d_redo, b->d_chunk_off, b->d_blk_doc,
+  void *ptrs[] = {b->d_text_own, b->d_off_own, b->d_sym, b->d_rsbits, b->d_bits, b->d_acc, b->d_redo, b->d_chunk_off, b->d_blk_doc,
                   b->d_lane_doc, b->d_lane_cnt, b->d_lane_start, b->d_lane_end, b->d_lane_plan,
                   b->d_seg_tab, b->d_seg_sum, b->d_seg_in,
                   b->d_tok_off,
@@ -873,7 +875,7 @@ extern "C" int dtk_batch_set_input(dtk_batch *b, const uint8_t *text, const uint
     if (doc_off[d + 1] - doc_off[d] >= 0x7FFFFFF0ull) return DTK_E_ARG;  // 31-bit cursor positions
   }
   const uint64_t total = doc_off[n_docs];
-  if (total > b->max_bytes) return DTK_E_CAPACITY;
+  if (total > b->max_bytes || total + n_docs + 64 >= (1ull << 32)) return DTK_E_CAPACITY;  // 32-bit position bits
   if (total && !text) return DTK_E_ARG;
   HIP_TRY(hipStreamSynchronize(b->stream));  // previous run may still read the buffers
   if (total) HIP_TRY(hipMemcpyAsync(b->d_text_own, text, total, hipMemcpyHostToDevice, b->stream));
@@ -897,7 +899,7 @@ extern "C" int dtk_batch_set_input(dtk_batch *b, const uint8_t *text, const uint
 extern "C" int dtk_batch_set_input_device(dtk_batch *b, const void *d_text, const void *d_doc_off,
                                           uint32_t n_docs, uint64_t total_bytes) {
   if (!b || !d_doc_off || n_docs == 0 || (total_bytes && !d_text)) return DTK_E_ARG;
-  if (n_docs > b->max_docs || total_bytes > b->max_bytes) return DTK_E_CAPACITY;
+  if (n_docs > b->max_docs || total_bytes > b->max_bytes || total_bytes + n_docs + 64 >= (1ull << 32)) return DTK_E_CAPACITY;
   b->d_text = (const uint8_t *)d_text;
   b->d_off = (const uint64_t *)d_doc_off;
   b->n_docs = n_docs;
@@ -955,7 +957,7 @@ static int plan_lanes(dtk_batch *b) {
     const uint64_t want_lanes = 4ull * 65536ull;
     uint64_t c = b->total / want_lanes;
     uint32_t p2 = 128;
-    while (p2 * 2 <= c && p2 < 1024) p2 <<= 1;
+    while (p2 * 2 <= c && p2 < DTK_LDS_BIT_CHUNK_MAX) p2 <<= 1;  // (up to what a wave's LDS bitmaps cover)
     C = p2;
   }
   b->chunk = C;
@@ -1031,7 +1033,7 @@ static int plan_lanes(dtk_batch *b) {
 static DtkWalkArgs walk_args(dtk_batch *b) {
   DtkWalkArgs w{};
   w.sym = b->d_sym; w.doc_off = b->d_off; w.n_docs = b->n_docs;
-  w.evA = b->d_evA; w.evB = b->d_evB; w.status = b->d_status;
+  w.bits = b->d_bits; w.bit_words = b->bit_words; w.doc_tail = b->d_doc_tail; w.status = b->d_status;
   w.tok_cnt = b->d_tok_cnt; w.sent_cnt = b->d_sent_cnt; w.text_cnt = b->d_text_cnt;
   w.steps = (unsigned long long *)(b->d_totals + 4);
   w.step_factor = 2048;  // look-ahead is bounded by the 1024-rune window (matrix.go:365)
@@ -1053,12 +1055,10 @@ static DtkSpecArgs spec_args(dtk_batch *b, bool redo) {
     s.warm_min = e2 ? (uint32_t)atoi(e2) : 0u;
     static const char *e5 = getenv("DATOK_WARM_EXTEND");
     s.warm_extend = e5 ? (uint32_t)atoi(e5) : b->cfg_extend;
-    // Event bytes through LDS lists pay off when the batch's event arrays no longer fit the L2
-    // (measured: +10 % at 256 MiB, +3..8 % at 64 MiB, -3 % at 16 MiB).  DATOK_EV_LISTS=0/1 forces, DATOK_EV_LISTS_MIN moves the limit.
-    static const char *e3 = getenv("DATOK_EV_LISTS");
-    static const char *e4 = getenv("DATOK_EV_LISTS_MIN");
-    const uint64_t lim = e4 ? (uint64_t)atoll(e4) : (48ull << 20);
-    s.ev_lists = e3 ? (uint32_t)(atoi(e3) != 0) : (uint32_t)(b->total >= lim);
+    // the walk collects its event bits in LDS, one set of bitmaps per wave (DATOK_LDS_BITS=0: straight to memory)
+    static const char *e3 = getenv("DATOK_LDS_BITS");
+    const bool lds = e3 ? atoi(e3) != 0 : true;
+    s.lds_words = (lds && b->chunk <= DTK_LDS_BIT_CHUNK_MAX) ? DTK_LDS_BIT_WORDS(b->chunk) : 0u;
   }
   return s;
 }
@@ -1126,11 +1126,10 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
     b->d_status = (uint32_t *)q; q += nd * 4;
     b->d_first_bad = (uint32_t *)q; q += nd * 4;
     b->d_fail_lane = (uint32_t *)q; q += nd * 4;
+    b->d_doc_tail = (uint32_t *)q; q += nd * 4;
     const size_t acc_used = ((size_t)(q - b->d_acc) + 15) & ~(size_t)15;  // the block has 64 bytes of slack
-    const size_t ev_bytes = (b->total + 4 * nd + 4 + 255) & ~(size_t)255;
-    b->d_evA = b->d_ev;
-    b->d_evB = b->d_ev + ev_bytes;
-    if (dtk_launch_clear2(b->d_acc, acc_used, b->d_ev, (skip & 4) ? 0 : 2 * ev_bytes, s))
+    b->bit_words = (uint32_t)(((b->total + nd) / 32 + 8) & ~(uint64_t)3);  // 16-byte multiples per kind
+    if (dtk_launch_clear2(b->d_acc, acc_used, b->d_bits, (skip & 4) ? 0 : (size_t)EVB_KINDS * b->bit_words * 4, s))
       return hip_fail(hipGetLastError(), "clear");
   }
   STAGE(1);
@@ -1166,7 +1165,7 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
   }
   DtkCompactArgs c{};
   c.text = b->d_text; c.rs_bits = b->d_rsbits; c.doc_off = b->d_off; c.n_docs = b->n_docs;
-  c.evA = b->d_evA; c.evB = b->d_evB; c.status = b->d_status;
+  c.bits = b->d_bits; c.bit_words = b->bit_words; c.doc_tail = b->d_doc_tail; c.status = b->d_status;
   c.flags = flags & DTK_NEWLINE_AFTER_EOT; c.kind = m->kind;
   c.tok_off = b->d_tok_off; c.sent_off = b->d_sent_off; c.text_off = b->d_text_off;
   c.totals = b->d_totals;
@@ -1290,11 +1289,10 @@ static int finish(dtk_batch *b) {
     while ((uint32_t)b->h_totals[5] != 0) {
       b->repair_rounds++;
       DtkSpecArgs sp = spec_args(b, true);
-      sp.first_repair = b->repair_rounds == 1u ? 1u : 0u;
       HIP_TRY(hipMemsetAsync(n_bad, 0, 8, s));
       // spread + reset, clear, then the stages of the first pass restricted to what is repaired
       if (dtk_launch_spec(&m->tab, &w, &sp, 5, cmp_mask_of(m), b->d_redo, n_bad, s) ||
-          dtk_launch_redo_clear(&w, &sp, b->d_blk_doc, b->total, s))
+          dtk_launch_redo_clear(&w, &sp, s))
         return hip_fail(hipGetLastError(), "speculative repair");
       for (int stage = 1; stage <= 4; stage++)
         if (dtk_launch_spec(&m->tab, &w, &sp, stage, cmp_mask_of(m), b->d_redo, n_bad, s))
@@ -1365,7 +1363,7 @@ extern "C" int dtk_batch_result_device(dtk_batch *b, dtk_result_view *o) {
   o->tok_rstart = b->d_rstart; o->tok_rend = b->d_rend;
   o->tok_bstart = b->d_bstart; o->tok_bend = b->d_bend;
   o->sent = b->d_sent; o->text_tok_end = b->d_ttok; o->text_sent_end = b->d_tsent;
-  o->status = b->d_status; o->events = b->d_evA; o->events_open = b->d_evB;
+  o->status = b->d_status; o->ev_bits = b->d_bits; o->ev_words = b->bit_words; o->doc_tail = b->d_doc_tail;
   o->n_exact = (uint32_t)b->h_exact_ids.size();
   o->exact_doc = b->d_exact_ids; o->exact_off = b->d_exact_off; o->calls = (const dtk_call *)b->d_calls;
   return DTK_OK;
@@ -1392,13 +1390,13 @@ extern "C" int dtk_batch_result_host(dtk_batch *b, dtk_result_view *o) {
   if ((rc = get(b->h_ttok, b->d_ttok, nx))) return rc;
   if ((rc = get(b->h_tsent, b->d_tsent, nx))) return rc;
   if ((rc = get(b->h_status, b->d_status, nd))) return rc;
-  if ((rc = get(b->h_events, b->d_evA, b->total + 4 * nd + 4))) return rc;
-  if ((rc = get(b->h_events_b, b->d_evB, b->total + 4 * nd + 4))) return rc;
+  if ((rc = get(b->h_bits, b->d_bits, (uint64_t)EVB_KINDS * b->bit_words))) return rc;
+  if ((rc = get(b->h_doc_tail, b->d_doc_tail, nd))) return rc;
   o->tok_off = b->h_tok_off.data(); o->sent_off = b->h_sent_off.data(); o->text_off = b->h_text_off.data();
   o->tok_rstart = b->h_rstart.data(); o->tok_rend = b->h_rend.data();
   o->tok_bstart = b->h_bstart.data(); o->tok_bend = b->h_bend.data();
   o->sent = b->h_sent.data(); o->text_tok_end = b->h_ttok.data(); o->text_sent_end = b->h_tsent.data();
-  o->status = b->h_status.data(); o->events = b->h_events.data(); o->events_open = b->h_events_b.data();
+  o->status = b->h_status.data(); o->ev_bits = b->h_bits.data(); o->ev_words = b->bit_words; o->doc_tail = b->h_doc_tail.data();
   o->n_exact = (uint32_t)b->h_exact_ids.size();
   o->exact_doc = b->h_exact_ids.data(); o->exact_off = b->h_exact_off.data(); o->calls = (const dtk_call *)b->h_calls.data();
   return DTK_OK;

@@ -24,34 +24,34 @@
 // the lean walk's per-lane window of the symbol stream in LDS: entries, and u16 per row (72 B)
 #define DTK_WIN 32u
 #define DTK_WIN_ROW 36u
-// the lean walk's per-lane list of event bytes in LDS: entries, fill level at which the wave writes
-// its lists out, dwords per row (odd: the rows of the 64 lanes start in different banks)
-#define DTK_ELIST 16u
-#define DTK_ELIST_HIGH 12u
-#define DTK_ELIST_ROW 17u
 
-// ---- event byte (one per byte position 0..len of every document); bit order is
-// the order in which the reference fires the calls at one cursor position: the
-// cursor only reaches the byte behind an EOT by consuming it, which fires
-// SentenceEnd/TextEnd at once (matrix.go:593-600), so those precede a token that
-// ends there (possible for the double array only, which keeps its window).
+// ---- walk output: event bitmaps over cursor positions.  Position p (0..len) of document d, which starts at
+// input byte `off`, is bit  G = off + d + p  (one position more than the document has bytes, so the ranges of
+// consecutive documents follow each other without sharing a bit).  One bitmap per kind of event, `bit_words`
+// 32-bit words each, kind k at bits + k * bit_words; all cleared before a run.  Order of the calls at one cursor
+// position: SEOT, TEOT (the cursor only reaches the byte behind an EOT by consuming it, which fires SentenceEnd /
+// TextEnd at once, matrix.go:593-600), END (a token that ends there: double array only, which keeps its window),
+// SEPS.  START is no call: it marks the first byte of the token whose END is the next END bit.
+// The final SentenceEnd / TextEnd (matrix.go:683-691) are two bits of the document's tail word, with the
+// cursor they fire at:  doc_tail[d] = cursor << 2 | 1 (SentenceEnd) | 2 (TextEnd).
+// The walk collects END / START / SEPS bits in LDS (one set of bitmaps per wave, covering the positions of its
+// 64 chunk lanes) and writes whole words out at the end: one scattered byte store per event cost a third of the
+// pipeline's throughput (each reaches memory as its own partial-sector write).
+enum { EVB_END = 0, EVB_START = 1, EVB_SEPS = 2, EVB_TEOT = 3, EVB_SEOT = 4, EVB_KINDS = 5 };
+#define DTK_EV_BIT(off, d) ((uint64_t)(off) + (uint64_t)(d))
+#define DTK_TAIL_S 1u
+#define DTK_TAIL_E 2u
+// LDS words per kind for a wave of 64 chunk lanes of `chunk` bytes: 64 * (chunk + 1) positions + alignment slack
+#define DTK_LDS_BIT_WORDS(chunk) (2u * (chunk) + 8u)
+#define DTK_LDS_BIT_CHUNK_MAX 256u  // larger chunks write their bits straight to memory
+
+// flags of one queued cursor position inside the compaction (bit order = call order)
 #define EV_S_EOT 0x01u
 #define EV_E_EOT 0x02u
 #define EV_TOK_END 0x04u
 #define EV_S_EPS 0x08u
-#define EV_S_EPS2 0x10u
 #define EV_S_EOF 0x20u
 #define EV_E_EOF 0x40u
-#define EV_TOK_START 0x80u  // opening byte of the position where a token of >= EV_LEN_LONG bytes starts
-#define EV_LEN_SHIFT 3      // closing byte, bits 3-7: byte length of the token that ends here, or EV_LEN_LONG
-#define EV_LEN_LONG 31u
-#define EV_SMASK (EV_S_EOT | EV_S_EPS | EV_S_EPS2 | EV_S_EOF)
-#define EV_EMASK (EV_E_EOT | EV_E_EOF)
-
-// Index of position 0 of document d (starting at input byte `off`) in the two event
-// arrays: 4-byte aligned so that four positions load as one dword, and
-// one position more than the document has bytes.  Needs total + 4 * n_docs + 4 slots.
-#define DTK_EV_BASE(off, d) ((((uint64_t)(off)) + 4ull * (uint64_t)(d)) & ~3ull)
 
 // per-document status (mirrors DTK_ST_* of datok_gpu.h)
 #define ST_WINDOW_OVERFLOW 1u
@@ -125,7 +125,7 @@ struct DtkLaneCount {
   // for compacting a long document in segments (k_seg_*): SentenceEnd calls, and the lane's last
   // TextEnd fired by an EOT: its position (0xFFFFFFFF = none) and the lane's Token calls before it
   uint32_t sev, e_pos, e_tok;
-  uint32_t pad;  // the closing byte the lane stopped with (k_redo_reset puts it back in the first repair round)
+  uint32_t pad;
 };
 struct DtkSpecArgs {
   uint32_t n_lanes;
@@ -144,14 +144,16 @@ struct DtkSpecArgs {
   uint32_t warm_min;                // ... looking backwards from chunk start - warm_min
   uint32_t first_repair;            // repair rounds: 1 in the round that follows the first pass
   uint32_t warm_extend;             // move the warm-up start back to the previous blank, at most this many bytes (0: off)
-  uint32_t ev_lists;                // lean walk: collect event bytes in LDS lists (large batches), 0: plain stores
+  uint32_t lds_words;               // LDS bitmap words per kind for one wave (0: event bits go straight to memory)
 };
 
 struct DtkWalkArgs {
   const uint16_t *sym;      // symbol stream, one entry per input byte
   const uint64_t *doc_off;  // n_docs + 1
   uint32_t n_docs;
-  uint8_t *evA, *evB;       // closing / opening event bytes, zero-filled; index DTK_EV_BASE + p
+  uint32_t *bits;           // event bitmaps (EVB_KINDS x bit_words words), zero-filled
+  uint32_t bit_words;
+  uint32_t *doc_tail;       // per document, zero-filled
   uint32_t *status;         // per document, OR-ed
   uint64_t *tok_cnt, *sent_cnt, *text_cnt;  // per document: what the writer would have collected
   unsigned long long *steps;  // global lookup counter
@@ -163,7 +165,9 @@ struct DtkCompactArgs {
   const uint32_t *rs_bits;  // bit g: input byte g starts a rune (k_symbolize)
   const uint64_t *doc_off;
   uint32_t n_docs;
-  const uint8_t *evA, *evB;
+  const uint32_t *bits;     // event bitmaps of the walk
+  uint32_t bit_words;
+  const uint32_t *doc_tail;
   uint32_t *status;
   uint32_t flags;           // DTK_NEWLINE_AFTER_EOT
   int kind;                 // matrix / double array (EOT rewind rule differs)
@@ -269,8 +273,7 @@ int dtk_launch_walk(const struct DtkTableDev *tab, const struct DtkWalkArgs *arg
 int dtk_launch_spec(const struct DtkTableDev *tab, const struct DtkWalkArgs *args,
                     const struct DtkSpecArgs *spec, int stage, uint32_t cmp_mask, uint32_t *redo_out,
                     uint32_t *n_bad, void *stream);
-int dtk_launch_redo_clear(const struct DtkWalkArgs *args, const struct DtkSpecArgs *spec, const uint32_t *blk_doc,
-                          uint64_t total, void *stream);
+int dtk_launch_redo_clear(const struct DtkWalkArgs *args, const struct DtkSpecArgs *spec, void *stream);
 int dtk_launch_compact(const struct DtkCompactArgs *args, int pass, void *stream);
 int dtk_launch_exact(const struct DtkTableDev *tab, const struct DtkExactArgs *args, void *stream);
 int dtk_launch_seg_prepare(const struct DtkCompactArgs *args, const uint32_t *doc_seg0, void *stream);

@@ -373,37 +373,31 @@ struct DaTrans {
   }
 };
 
-// Events are stored lane-privately, one byte per cursor position, in two arrays:
-// "closing" calls (S_EOT, E_EOT, TOK_END: what a rewind of the window fires) and
-// "opening" calls (the SentenceEnd / TextEnd fired afterwards), so that the lane
-// whose walk ends with a rewind at position q and the lane that starts from q
-// never store to the same byte.  A token is recorded by a TOK_END bit in the
-// closing byte of its end position, with its byte length in the upper five bits of
-// that byte; a token of 31 bytes or more (length field saturated) also sets a
-// TOK_START bit in the opening byte of its start position, and the compaction pairs
-// such starts and ends up.  Rune lengths come from the rune-start bitmap.  Cursor positions of successive events
-// never decrease for the matrix walk, and no byte is written twice except in the
-// cases tracked here in registers (a second epsilon SentenceEnd at one cursor;
-// for the double array a token that ends where an EOT fired, datok.go:1019-1030
-// keeps its window).  A lane only stores inside its window
-//   opening: lo <= pos < hi      closing: lo < pos <= hi
-// (whole document: lo = 0, hi = 0xFFFFFFFF); an event outside is dropped and
-// remembered, the check pass then knows the lane left its window.
-//
-// The lean walk does not store its event bytes one by one: a single-byte store every few
-// iterations from each of 64 lanes, to 64 different lines, keeps more dirty lines in flight than
-// the L2 holds (measured: without the stores the walk of a large batch takes 37 % less time).
-// The lane appends (position, array, byte) to a private list in LDS instead (elist, DTK_ELIST
-// entries of  (pos - lo) << 9 | array << 8 | byte ); the wave writes its lists out together when
-// one of them runs full and at the end, so that the stores to one line arrive back to back.
+// What the walk reports: one bit per event in the bitmap of its kind (dtk_internal.h).  Token ends, token starts
+// and epsilon SentenceEnds -- three bits per token and a bit -- are OR-ed into the wave's bitmaps in LDS, which the
+// wave writes out as whole words when its lanes are done; the rare kinds (EOT calls) and positions outside the
+// wave's range (a lane's last token may end far behind its chunk) go straight to memory.  A lane only reports inside
+// its window
+//   opening kinds (START, SEPS): lo <= pos < hi      closing kinds (END, TEOT, SEOT): lo < pos <= hi
+// (whole document: lo = 0, hi = 0xFFFFFFFF); an event outside is dropped and remembered, the check pass then
+// knows the lane left its window.
+// Calls the bitmaps cannot order flag the document ST_IRREGULAR for the exact pass: a second epsilon SentenceEnd
+// at one cursor, a Token call with an empty surface or a negative one (two starts or two ends on one bit), an
+// EOT fired twice at one position (double array, datok.go:1019-1030 keeps its window).
+// (an LDS pointer that stays one: through a plain pointer the compiler loses the address space and emits FLAT atomics)
+typedef __attribute__((address_space(3))) uint32_t dtk_lds_u32;
+
 struct EventSink {
-  uint8_t *evA;        // closing bytes, index = position in the document
-  uint64_t dB;         // the opening bytes are at evA + dB
+  uint32_t *g;         // the batch's bitmaps
+  uint32_t gw;         // words per kind
+  uint32_t gb;         // bit of position 0 of the document
+  dtk_lds_u32 *lds;    // the wave's bitmaps in LDS (END, START, SEPS); lw == 0: none
+  uint32_t lw;         // words per kind there
+  uint32_t w0;         // global word of LDS word 0
+  uint32_t *tailw;     // the document's tail word
   uint32_t lo, hi;     // window
-  uint32_t *elist;     // the lane's list in LDS (nullptr: plain stores)
-  uint32_t ecount;
-  uint32_t last_s_p, s_bits;      // position / byte of the last opening SentenceEnd
-  uint32_t last_eot_p, eot_bits;  // position / byte of the last EOT pair (double array merge)
+  uint32_t last_s_p;   // position of the last epsilon SentenceEnd
+  uint32_t last_eot_p; // position of the last EOT pair
   uint32_t st;
   uint32_t dropped;
   // what NewTokenWriter would have collected from this lane's calls
@@ -411,55 +405,34 @@ struct EventSink {
   uint32_t c_tok, c_sent, c_text;
   uint32_t c_sev;         // SentenceEnd calls (all of them, also where the reference would panic)
   uint32_t e_pos, e_tok;  // the last EOT TextEnd of this lane: position, Token calls before it
-  uint32_t last_c;        // the last closing byte of this lane (the one at the position where it stops)
-  __device__ __forceinline__ void init(uint8_t *a, uint8_t *b, uint32_t wlo, uint32_t whi,
-                                       uint32_t *list = nullptr) {
-    evA = a; dB = (uint64_t)(b - a); lo = wlo; hi = whi; elist = list; ecount = 0;
-    last_s_p = last_eot_p = 0xFFFFFFFFu; s_bits = eot_bits = 0; st = 0; dropped = 0;
+  __device__ __forceinline__ void init(const DtkWalkArgs &A, uint64_t off, uint32_t d, uint32_t wlo, uint32_t whi,
+                                       uint32_t *lds_bits = nullptr, uint32_t lds_words = 0, uint32_t word0 = 0) {
+    g = A.bits; gw = A.bit_words; gb = (uint32_t)DTK_EV_BIT(off, d); tailw = A.doc_tail ? A.doc_tail + d : nullptr;
+    lds = (dtk_lds_u32 *)lds_bits; lw = lds_bits ? lds_words : 0u; w0 = word0;
+    lo = wlo; hi = whi;
+    last_s_p = last_eot_p = 0xFFFFFFFFu; st = 0; dropped = 0;
     c_tok = c_sent = c_text = 0;
-    c_sev = 0; e_pos = 0xFFFFFFFFu; e_tok = 0; last_c = 0;
+    c_sev = 0; e_pos = 0xFFFFFFFFu; e_tok = 0;
   }
-  // writes the listed bytes; lanes of a wave call it together (the loop runs to the longest list)
-  __device__ __forceinline__ void flush() {
-#pragma unroll 1
-    for (uint32_t i = 0; i < ecount; i++) {
-      const uint32_t e = elist[i];
-      evA[(uint64_t)lo + (e >> 9) + ((e & 256u) ? dB : 0ull)] = (uint8_t)e;
-    }
-    ecount = 0;
-  }
-  // arr: 0 closing, 1 opening;  pos is inside the window (>= lo).  The walk writes its lists out
-  // before one can run full (at most 3 bytes per iteration); the plain store is for lanes without
-  // a list and for windows of 8 MiB and more.
-  __device__ __forceinline__ void put(uint32_t arr, uint32_t pos, uint32_t v) {
+  __device__ __forceinline__ void put(uint32_t kind, uint32_t pos) {
     if (DTK_KO & 8) return;
-    const uint32_t rel = pos - lo;
-    if (elist != nullptr && rel < (1u << 23) && ecount < DTK_ELIST) {
-      elist[ecount++] = (rel << 9) | (arr << 8) | (v & 255u);
-      return;
-    }
-    evA[(uint64_t)pos + (arr ? dB : 0ull)] = (uint8_t)v;
+    const uint32_t G = gb + pos, m = 1u << (G & 31u), w = (G >> 5) - w0;
+    if (w < lw) __hip_atomic_fetch_or(&lds[kind * lw + w], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_or_b32
+    else atomicOr(&g[kind * gw + (G >> 5)], m);
   }
   __device__ __forceinline__ bool in_closing(uint32_t p) const { return p > lo && p <= hi; }
   __device__ __forceinline__ bool in_opening(uint32_t p) const { return p >= lo && p < hi; }
 
   // Token(bufft, buffer[:buffc]) -- matrix.go:528,569,675
   // sent_first: no token since the last SentenceEnd / TextEnd (the writer's sentB)
-  // (bs: byte position of buffer[0], the last rewind -- only the exact pass, ExactSink, needs it)
   template <bool IS_MATRIX>
   __device__ __forceinline__ void token(uint32_t /*bs*/, uint32_t tp, uint32_t p, bool sent_first) {
     if (!in_closing(p)) { dropped = 1; return; }
     c_tok++;
     c_sent += sent_first ? 1u : 0u;
-    uint32_t bits = EV_TOK_END;
-    if (!IS_MATRIX && p == last_eot_p) bits |= eot_bits;
-    // the byte length rides in the upper five bits of the closing byte; a token of 31 bytes or
-    // more additionally marks its start in the opening byte of its first position (a SentenceEnd
-    // may have fired at that cursor before: same byte, stored by this lane)
-    const uint32_t bl = p - tp;
-    last_c = bits | ((bl < EV_LEN_LONG ? bl : EV_LEN_LONG) << EV_LEN_SHIFT);
-    put(0u, p, last_c);
-    if (bl >= EV_LEN_LONG) put(1u, tp, EV_TOK_START | (tp == last_s_p ? s_bits : 0u));
+    if (p <= tp) st |= ST_IRREGULAR;
+    put(EVB_END, p);
+    put(EVB_START, tp);
   }
   // SentenceEnd? + TextEnd fired by an EOT rune -- matrix.go:593-600
   // has_tok: the current text has a token (else the reference panics in position modes)
@@ -470,11 +443,10 @@ struct EventSink {
     c_sev += with_sentence ? 1u : 0u;
     e_pos = p; e_tok = c_tok;
     if (has_tok) c_sent += with_sentence ? 1u : 0u; else st |= ST_EMPTY_TEXT;
-    if (!IS_MATRIX && p == last_eot_p) st |= ST_IRREGULAR;  // the same EOT consumed twice
-    const uint32_t bits = EV_E_EOT | (with_sentence ? EV_S_EOT : 0u);
-    if (!IS_MATRIX) { last_eot_p = p; eot_bits = bits; }
-    last_c = bits;
-    put(0u, p, bits);
+    last_eot_p = p;
+    const uint32_t G = gb + p, m = 1u << (G & 31u);
+    if (atomicOr(&g[EVB_TEOT * gw + (G >> 5)], m) & m) st |= ST_IRREGULAR;  // the same EOT fired before (by any lane)
+    if (with_sentence) atomicOr(&g[EVB_SEOT * gw + (G >> 5)], m);
   }
   // SentenceEnd from an epsilon arc on an empty token -- matrix.go:574-575
   template <bool IS_MATRIX>
@@ -482,27 +454,52 @@ struct EventSink {
     if (!in_opening(p)) { dropped = 1; return; }
     c_sev++;
     if (has_tok) c_sent++; else st |= ST_EMPTY_TEXT;
-    if (p == last_s_p) {
-      if (s_bits & EV_S_EPS2) st |= ST_IRREGULAR;
-      s_bits |= EV_S_EPS2;
-    } else {
-      last_s_p = p;
-      s_bits = EV_S_EPS;
-    }
-    put(1u, p, s_bits);
+    if (p == last_s_p) st |= ST_IRREGULAR;
+    last_s_p = p;
+    put(EVB_SEPS, p);
   }
   // final SentenceEnd / TextEnd -- matrix.go:683-691
   template <bool IS_MATRIX>
-  __device__ __forceinline__ void tail(uint32_t /*bs*/, uint32_t p, bool sentence_end, bool text_end, bool has_tok) {
-    const uint32_t bits = (sentence_end ? 0u : EV_S_EOF) | (text_end ? 0u : EV_E_EOF);
+  __device__ __forceinline__ void tail_(uint32_t p, bool sentence_end, bool text_end, bool has_tok) {
+    const uint32_t bits = (sentence_end ? 0u : DTK_TAIL_S) | (text_end ? 0u : DTK_TAIL_E);
     if (!bits) return;
     if (!in_opening(p)) { dropped = 1; return; }
     if (!text_end) c_text++;
     c_sev += sentence_end ? 0u : 1u;
     if (has_tok) c_sent += sentence_end ? 0u : 1u; else st |= ST_EMPTY_TEXT;
-    put(1u, p, bits | (p == last_s_p ? s_bits : 0u));
+    if (tailw && !(DTK_KO & 8)) *tailw = (p << 2) | bits;
   }
+  template <bool IS_MATRIX>
+  __device__ __forceinline__ void tail(uint32_t /*bs*/, uint32_t p, bool sentence_end, bool text_end, bool has_tok) {
+    tail_<IS_MATRIX>(p, sentence_end, text_end, has_tok);
+  }
+  __device__ __forceinline__ void flush() {}
 };
+
+// the wave's LDS bitmaps: cleared before the lanes walk, OR-ed into memory afterwards (all 64 lanes take part;
+// one wave per block, LDS operations of a wave complete in order)
+__device__ __forceinline__ void lds_bits_clear(uint32_t *lds_, uint32_t lw) {
+  dtk_lds_u32 *lds = (dtk_lds_u32 *)lds_;
+  for (uint32_t j = threadIdx.x; j < 3u * lw; j += WAVE) lds[j] = 0u;
+  __syncthreads();
+}
+__device__ __forceinline__ void lds_bits_flush(const uint32_t *lds_, uint32_t lw, uint32_t *g, uint32_t gw, uint32_t w0) {
+  const dtk_lds_u32 *lds = (const dtk_lds_u32 *)lds_;
+  __syncthreads();
+  for (uint32_t j = threadIdx.x; j < lw; j += WAVE) {
+    if (w0 + j >= gw) break;
+#pragma unroll
+    for (uint32_t k = 0; k < 3u; k++) {
+      const uint32_t v = lds[k * lw + j];
+      if (v) atomicOr(&g[k * gw + w0 + j], v);
+    }
+  }
+}
+// global word of LDS word 0 for the wave whose first lane is L0
+__device__ __forceinline__ uint32_t lds_bits_word0(const DtkWalkArgs &A, const DtkSpecArgs &S, uint32_t L0) {
+  const uint32_t d0 = S.lane_doc[L0];
+  return (uint32_t)((DTK_EV_BIT(A.doc_off[d0], d0) + (uint64_t)(L0 - S.chunk_off[d0]) * S.chunk) >> 5);
+}
 
 template <typename TRANS>
 __device__ __forceinline__ uint32_t guard_of(const TRANS &tr) {
@@ -912,8 +909,6 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
       }
     }
     if (!done && !backtrack) { DTK_EOF_DRAIN() }
-    // one list of the wave is nearly full: all lanes write theirs out
-    if (MODE != MODE_START && __builtin_amdgcn_ballot_w64(sink.ecount >= DTK_ELIST_HIGH) != 0ull) sink.flush();
   }
 #undef DTK_EOF_DRAIN
 
@@ -927,7 +922,6 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
       sink.template tail<true>(bs, p, (F & 1u) != 0, (F & 2u) != 0, (F & 8u) != 0);  // matrix.go:683-691
     }
   }
-  if (MODE != MODE_START) sink.flush();
   st_out = st;
   steps_out = it;  // lookups
 }
@@ -1091,16 +1085,13 @@ __global__ __launch_bounds__(WAVE) void k_walk_doc(TRANS tr, DtkWalkArgs A, uint
                                                    uint32_t unknown, uint32_t identity) {
   __shared__ uint16_t s_win[WAVE * DTK_WIN_ROW];
   uint16_t *win_row = s_win + threadIdx.x * DTK_WIN_ROW;
-  __shared__ uint32_t s_el[TRANS::LEAN ? WAVE * DTK_ELIST_ROW : 1];
-  uint32_t *el_row = TRANS::LEAN ? s_el + threadIdx.x * DTK_ELIST_ROW : nullptr;
   const uint32_t d = blockIdx.x * WAVE + threadIdx.x;
   uint32_t steps = 0;
   if (d < A.n_docs) {
     const uint64_t off = A.doc_off[d];
     const uint32_t len = (uint32_t)(A.doc_off[d + 1] - off);
     EventSink sink;
-    const uint64_t evb = DTK_EV_BASE(off, d);
-    sink.init(A.evA + evb, A.evB + evb, 0u, 0xFFFFFFFFu, el_row);
+    sink.init(A, off, d, 0u, 0xFFFFFFFFu);  // (documents of any length: the bits go straight to memory)
     DtkLaneState init{0u, tr.start_state(), tr.start_aux(), 0u}, fin;
     uint32_t st;
     walk_any<TRANS, IS_MATRIX, MODE_DOC>(tr, A.sym, off, len, init, 0u, sink, epsilon, unknown,
@@ -1195,8 +1186,8 @@ __device__ __forceinline__ DtkLaneState start_record(const TRANS &tr, const DtkW
       if (q < lim) q = lim;
       sp = q;
     }
-    EventSink sink;
-    sink.init(nullptr, nullptr, 0u, 0u);
+    EventSink sink;  // (a warm-up reports nothing)
+    sink.g = nullptr; sink.lds = (dtk_lds_u32 *)nullptr; sink.tailw = nullptr; sink.lw = 0; sink.lo = sink.hi = 0;
     uint32_t st;
     if (sp > 0) {
       while (sp < len && !DTK_SYM_IS_START(s[sp])) sp++;
@@ -1234,15 +1225,18 @@ __global__ __launch_bounds__(WAVE) void k_spec_start(TRANS tr, DtkWalkArgs A, Dt
 // to its first sync point at or behind the end of its chunk -- which is the record its successor
 // finds for itself if the speculation holds, and k_spec_verify checks exactly that.  Every lane
 // with a record walks; what lanes behind a broken chain stored is cleared by the repair round.
-template <typename TRANS, bool IS_MATRIX, bool LISTS>
+extern __shared__ uint32_t s_dyn_bits[];  // the wave's event bitmaps (3 kinds x S.lds_words), if any
+
+template <typename TRANS, bool IS_MATRIX>
 __global__ __launch_bounds__(WAVE) void k_spec_both(TRANS tr, DtkWalkArgs A, DtkSpecArgs S,
                                                     uint32_t epsilon, uint32_t unknown,
                                                     uint32_t identity) {
   __shared__ uint16_t s_win[WAVE * DTK_WIN_ROW];
   uint16_t *win_row = s_win + threadIdx.x * DTK_WIN_ROW;
-  __shared__ uint32_t s_el[LISTS ? WAVE * DTK_ELIST_ROW : 1];
-  uint32_t *el_row = LISTS ? s_el + threadIdx.x * DTK_ELIST_ROW : nullptr;
+  uint32_t *lds_bits = S.lds_words ? s_dyn_bits : nullptr;
   const uint32_t L = blockIdx.x * WAVE + threadIdx.x;
+  const uint32_t w0 = S.lds_words ? lds_bits_word0(A, S, blockIdx.x * WAVE) : 0u;
+  if (lds_bits) lds_bits_clear(lds_bits, S.lds_words);
   uint32_t steps = 0;
   if (L < S.n_lanes) {
     const uint32_t d = S.lane_doc[L];
@@ -1262,19 +1256,19 @@ __global__ __launch_bounds__(WAVE) void k_spec_both(TRANS tr, DtkWalkArgs A, Dtk
       fin.flags &= (LANE_F_SENT | LANE_F_TEXT | LANE_F_OK);
     } else if (rec.p != 0xFFFFFFFFu) {
       EventSink sink;
-      const uint64_t evb = DTK_EV_BASE(off, d);
-      sink.init(A.evA + evb, A.evB + evb, rec.p, 0xFFFFFFFFu, el_row);
+      sink.init(A, off, d, rec.p, 0xFFFFFFFFu, lds_bits, S.lds_words, w0);
       uint32_t st = 0, steps2 = 0;
       walk_any<TRANS, IS_MATRIX, MODE_CHUNK>(tr, A.sym, off, len, rec, stop, sink, epsilon, unknown,
                                               identity, step_cap(A.step_factor, len), fin, st, steps2, win_row);
       steps += steps2;
       if (sink.dropped) fin.flags |= LANE_F_DROPPED;
       cnt.tok = sink.c_tok; cnt.sent = sink.c_sent; cnt.text = sink.c_text; cnt.status = st | sink.st;
-      cnt.sev = sink.c_sev; cnt.e_pos = sink.e_pos; cnt.e_tok = sink.e_tok; cnt.pad = sink.last_c;
+      cnt.sev = sink.c_sev; cnt.e_pos = sink.e_pos; cnt.e_tok = sink.e_tok;
     }
     S.lane_end[L] = fin;
     S.lane_cnt[L] = cnt;
   }
+  if (lds_bits) lds_bits_flush(lds_bits, S.lds_words, A.bits, A.bit_words, w0);
   add_steps(A.steps, steps);
 }
 
@@ -1317,15 +1311,16 @@ __global__ __launch_bounds__(256) void k_spec_link(DtkSpecArgs S) {
   if (!linked) atomicMax(&S.first_bad[d], ~(L - L0));  // stored inverted: zero fill = none
 }
 
-template <typename TRANS, bool IS_MATRIX, bool LISTS>
+template <typename TRANS, bool IS_MATRIX>
 __global__ __launch_bounds__(WAVE) void k_spec_walk(TRANS tr, DtkWalkArgs A, DtkSpecArgs S,
                                                     uint32_t epsilon, uint32_t unknown,
                                                     uint32_t identity) {
   __shared__ uint16_t s_win[WAVE * DTK_WIN_ROW];
   uint16_t *win_row = s_win + threadIdx.x * DTK_WIN_ROW;
-  __shared__ uint32_t s_el[LISTS ? WAVE * DTK_ELIST_ROW : 1];
-  uint32_t *el_row = LISTS ? s_el + threadIdx.x * DTK_ELIST_ROW : nullptr;
+  uint32_t *lds_bits = S.lds_words ? s_dyn_bits : nullptr;
   const uint32_t L = blockIdx.x * WAVE + threadIdx.x;
+  const uint32_t w0 = S.lds_words ? lds_bits_word0(A, S, blockIdx.x * WAVE) : 0u;
+  if (lds_bits) lds_bits_clear(lds_bits, S.lds_words);
   uint32_t steps = 0;
   if (L < S.n_lanes) {
     const uint32_t d = S.lane_doc[L];
@@ -1344,19 +1339,19 @@ __global__ __launch_bounds__(WAVE) void k_spec_walk(TRANS tr, DtkWalkArgs A, Dtk
         const uint32_t len = (uint32_t)(A.doc_off[d + 1] - off);
         const DtkLaneState init = S.lane_start[L];
         EventSink sink;
-        const uint64_t evb = DTK_EV_BASE(off, d);
-        sink.init(A.evA + evb, A.evB + evb, init.p, pl.wend, el_row);
+        sink.init(A, off, d, init.p, pl.wend, lds_bits, S.lds_words, w0);
         uint32_t st = 0;
         walk_any<TRANS, IS_MATRIX, MODE_CHUNK>(tr, A.sym, off, len, init, pl.stop, sink, epsilon, unknown,
                                                 identity, step_cap(A.step_factor, len), fin, st, steps, win_row);
         if (sink.dropped) fin.flags |= LANE_F_DROPPED;
         cnt.tok = sink.c_tok; cnt.sent = sink.c_sent; cnt.text = sink.c_text; cnt.status = st | sink.st;
-        cnt.sev = sink.c_sev; cnt.e_pos = sink.e_pos; cnt.e_tok = sink.e_tok; cnt.pad = sink.last_c;
+        cnt.sev = sink.c_sev; cnt.e_pos = sink.e_pos; cnt.e_tok = sink.e_tok;
       }
       S.lane_end[L] = fin;
       S.lane_cnt[L] = cnt;
     }
   }
+  if (lds_bits) lds_bits_flush(lds_bits, S.lds_words, A.bits, A.bit_words, w0);
   add_steps(A.steps, steps);
 }
 
@@ -1420,12 +1415,20 @@ __global__ __launch_bounds__(256) void k_spec_verify(DtkWalkArgs A, DtkSpecArgs 
 // really ended is the true record of its successor: redo from `bad` on.
 __device__ __forceinline__ void mark_redo(const DtkSpecArgs &S, uint32_t d, uint32_t bad, uint32_t *redo_out,
                                           uint32_t *n_bad) {
-  const uint32_t L1 = S.chunk_off[d + 1];
+  const uint32_t L0 = S.chunk_off[d], L1 = S.chunk_off[d + 1];
   DtkLaneState en = S.lane_end[bad];
   en.flags &= (LANE_F_SENT | LANE_F_TEXT | LANE_F_OK);
   if (en.p != 0xFFFFFFFFu && bad + 1 < L1) S.lane_start[bad + 1] = en;
   // (ran to EOF: no later lane has a sync point -- k_redo_spread withdraws their records)
-  redo_out[d] = bad;
+  // The round walks again from the last lane before `bad` that owns anything: it started from a true record as
+  // well, and everything a lane behind the broken link can have reported lies behind that record -- the round
+  // clears from there on without having to tell true reports from false ones.
+  uint32_t r0 = bad;
+  if (bad > L0) {
+    r0 = bad - 1u;
+    while (r0 > L0 && S.lane_end[r0].p == S.lane_start[r0].p) r0--;
+  }
+  redo_out[d] = r0;
   atomicAdd(n_bad, 1u);
 }
 
@@ -1438,8 +1441,8 @@ __global__ __launch_bounds__(256) void k_spec_fix(DtkWalkArgs A, DtkSpecArgs S, 
   mark_redo(S, d, bad, redo_out, n_bad);
 }
 
-// ---- repair rounds (a document whose chain broke is redone from its first bad lane on).
-// All per lane / per document / per block of positions, so that a long document repairs as fast
+// ---- repair rounds (a document whose chain broke is redone from the last owning lane before its first bad lane on).
+// All per lane / per document / per bitmap word, so that a long document repairs as fast
 // as a batch of short ones:
 //   k_redo_spread : the first bad lane started from a true state, so k_spec_fix made its end the
 //                   record of its successor.  Further down the document, a lane whose predecessor
@@ -1447,15 +1450,16 @@ __global__ __launch_bounds__(256) void k_spec_fix(DtkWalkArgs A, DtkSpecArgs S, 
 //                   with high probability: its end becomes its successor's record too (speculation
 //                   again -- the next verification decides), so that one round repairs all isolated
 //                   misses of a document, not just the first.
-//   k_redo_reset  : per document, the counters and check words the round re-derives.
-//   k_redo_clear  : event bytes from the first redone position on.
+//   k_redo_reset  : per document, the counters and check words the round re-derives, and the tail word.
+//   k_redo_clear  : event bits behind the record the round walks from.
 // then k_spec_link, k_spec_walk (redone lanes only), k_spec_verify (repaired documents only), k_spec_fix.
 __global__ __launch_bounds__(256) void k_redo_spread(DtkSpecArgs S) {
   const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
   if (L >= S.n_lanes) return;
   const uint32_t d = S.lane_doc[L];
-  const uint32_t bad = S.redo_from[d];
-  if (bad == 0xFFFFFFFFu || L <= bad) return;
+  if (S.redo_from[d] == 0xFFFFFFFFu) return;
+  const uint32_t bad = ~S.fail_lane[d];  // the first lane that missed (k_redo_reset clears the word afterwards)
+  if (L <= bad) return;
   const uint32_t L1 = S.chunk_off[d + 1];
   if (S.lane_end[bad].p == 0xFFFFFFFFu) {  // the first bad lane ran to EOF: no later lane has a sync point
     S.lane_start[L].p = 0xFFFFFFFFu;
@@ -1470,82 +1474,60 @@ __global__ __launch_bounds__(256) void k_redo_spread(DtkSpecArgs S) {
   }
 }
 
-// First position whose event bytes a repair of document d from lane `bad` on must clear: the bad
-// lane's start record -- except in the first repair round.  In the first pass every lane with a
-// record has walked, also the lanes behind the broken link, from their own (wrong) records; those
-// lie at or behind the end of the bad lane's chunk, but can lie BEFORE the bad lane's record when
-// that record is behind its whole chunk (a token longer than a chunk: the lane owns nothing).
-// The first round therefore clears from the end of the bad lane's chunk if that is lower: every
-// lane before the first bad one checked out, the one that walked up to `from` did not rewind
-// between the end of its own chunk and `from` (events only happen at rewinds), and the lanes
-// between it and the bad one own nothing.  Later rounds find no such leftovers (lanes behind the
-// link stay off in a repair walk), and lanes before the bad one may then own positions below
-// their successor's chunk end.
-__device__ __forceinline__ uint32_t redo_low(const DtkSpecArgs &S, uint32_t d, uint32_t bad, uint32_t from) {
-  if (!S.first_repair) return from;
-  const unsigned long long chunk_end = (unsigned long long)(bad - S.chunk_off[d] + 1u) * S.chunk;
-  return chunk_end < from ? (uint32_t)chunk_end : from;
-}
-
 __global__ __launch_bounds__(256) void k_redo_reset(DtkWalkArgs A, DtkSpecArgs S) {
   const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d >= A.n_docs || S.redo_from[d] == 0xFFFFFFFFu) return;
   A.tok_cnt[d] = 0; A.sent_cnt[d] = 0; A.text_cnt[d] = 0; A.status[d] = 0;
   S.first_bad[d] = 0; S.fail_lane[d] = 0;
-  // the slot behind the last byte (k_redo_clear covers the positions that are bytes)
-  const uint64_t off = A.doc_off[d];
-  const uint32_t len = (uint32_t)(A.doc_off[d + 1] - off);
-  const uint32_t bad = S.redo_from[d];
-  const uint32_t from = S.lane_start[bad].p, low = redo_low(S, d, bad, from);
-  const uint64_t evb = DTK_EV_BASE(off, d);
-  if (len >= low) A.evB[evb + len] = 0;
-  if (len > from) A.evA[evb + len] = 0;
-  // First repair round: the closing byte at `from` belongs to the last lane before `bad` that owns
-  // anything (it stopped there), but a lane behind the link, walking from a wrong record, may have
-  // ended a token of its own at the same position in the first pass -- one byte, two writers.
-  // Put the owner's byte back (every lane keeps the closing byte it stopped with).
-  const uint32_t L0 = S.chunk_off[d];
-  if (S.first_repair && bad > L0 && from != 0xFFFFFFFFu && from <= len) {
-    uint32_t o = bad - 1u;
-    while (o > L0 && S.lane_end[o].p == S.lane_start[o].p) o--;  // lanes in between own nothing
-    if (S.lane_end[o].p == from && S.lane_start[o].p != from) A.evA[evb + from] = (uint8_t)S.lane_cnt[o].pad;
-  }
+  A.doc_tail[d] = 0;
 }
 
-// one block per DTK_SYM_BLOCK_BYTES input bytes; blk_doc[b] = document of the block's first byte
-__global__ __launch_bounds__(256) void k_redo_clear(DtkWalkArgs A, DtkSpecArgs S, const uint32_t *blk_doc,
-                                                    uint64_t total) {
-  const uint64_t g0 = (uint64_t)blockIdx.x * DTK_SYM_BLOCK_BYTES;
-  const uint32_t d_lo = blk_doc[blockIdx.x];
-  const uint32_t d_hi = min(blk_doc[blockIdx.x + 1], A.n_docs - 1u);
-  for (uint32_t i = threadIdx.x; i < DTK_SYM_BLOCK_BYTES; i += blockDim.x) {
-    const uint64_t g = g0 + i;
-    if (g >= total) break;
-    const uint32_t d = doc_of(A.doc_off, d_lo, d_hi + 1u, g);
-    const uint32_t bad = S.redo_from[d];
-    if (bad == 0xFFFFFFFFu) continue;
-    const uint64_t off = A.doc_off[d];
-    const uint32_t p = (uint32_t)(g - off), from = S.lane_start[bad].p, low = redo_low(S, d, bad, from);
-    const uint64_t evb = DTK_EV_BASE(off, d);
-    if (p >= low) A.evB[evb + p] = 0;
-    if (p > low && p != from) A.evA[evb + p] = 0;  // the closing byte at `from` belongs to the lane before
+// One thread per bitmap word.  In a repaired document every bit behind the record the round walks from is
+// cleared; at that very position only the opening kinds are (the closing kinds there were reported by the lane
+// that stopped at it: a true report that nobody makes again).
+__global__ __launch_bounds__(256) void k_redo_clear(DtkWalkArgs A, DtkSpecArgs S) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= A.bit_words) return;
+  const uint64_t G0 = 32ull * j, G1 = G0 + 32ull;
+  // the last document that starts at or before bit G0
+  uint32_t lo = 0, hi = A.n_docs;
+  while (hi - lo > 1) {
+    const uint32_t mid = lo + ((hi - lo) >> 1);
+    if (DTK_EV_BIT(A.doc_off[mid], mid) <= G0) lo = mid; else hi = mid;
+  }
+  uint32_t m_all = 0, m_open = 0;
+  for (uint32_t d = lo; d < A.n_docs; d++) {
+    const uint64_t key = DTK_EV_BIT(A.doc_off[d], d);
+    if (key >= G1) break;
+    const uint32_t r0 = S.redo_from[d];
+    if (r0 == 0xFFFFFFFFu) continue;
+    const uint32_t from = S.lane_start[r0].p;
+    if (from == 0xFFFFFFFFu) continue;
+    const uint64_t Gf = key + from, Ge = DTK_EV_BIT(A.doc_off[d + 1], d + 1);  // bits (Gf, Ge) and, opening kinds, Gf
+    const uint64_t a = Gf + 1 > G0 ? Gf + 1 : G0, b = Ge < G1 ? Ge : G1;
+    if (a < b) {
+      const uint32_t n = (uint32_t)(b - a), sh = (uint32_t)(a - G0);
+      const uint32_t m = (n >= 32u ? 0xFFFFFFFFu : ((1u << n) - 1u)) << sh;
+      m_all |= m; m_open |= m;
+    }
+    if (Gf >= G0 && Gf < G1) m_open |= 1u << (uint32_t)(Gf - G0);
+  }
+  if (m_all) {
+    A.bits[EVB_END * A.bit_words + j] &= ~m_all;
+    A.bits[EVB_TEOT * A.bit_words + j] &= ~m_all;
+    A.bits[EVB_SEOT * A.bit_words + j] &= ~m_all;
+  }
+  if (m_open) {
+    A.bits[EVB_START * A.bit_words + j] &= ~m_open;
+    A.bits[EVB_SEPS * A.bit_words + j] &= ~m_open;
   }
 }
 
 // ------------------------------------------------------------------ compact
 
-#define CQ_CAP 512u  // ring capacity in events (power of two; one light tile adds at most 256)
+#define CQ_CAP 512u  // ring capacity in queued positions (power of two; one light step adds at most 256)
 
-// One wave per document.  Light phase: 256 cursor positions per iteration (4 per
-// lane) -- combine the two event bytes (closing bits | opening bits, the token length
-// field of the closing byte kept aside), count rune starts from the bitmap, and append
-// the positions that carry events (about 0.3 per input byte) with their rune index to a
-// ring in LDS, using one packed wave scan.  Heavy phase: whenever 64 events are queued
-// (or at the end), lane i takes the i-th event and everything NewTokenWriter
-// tracks (token_writer.go:38-42: posC, pos, sentB, sent) is recovered with ballots,
-// popcounts of the lanes below and a handful of shuffles; wave-uniform carries link
-// the rounds.  Order of the calls at one position = bit order of the event byte.
-// Range of one segment of a long document: closing events in (p0, p1], opening events in
+// Range of one segment of a long document: closing kinds in (p0, p1], opening kinds in
 // [p0, p1) -- or [p0, p1] for the document's last segment.  false: nothing to do.
 struct SegRange { uint32_t d, p0, p1; bool first, last; };
 __device__ __forceinline__ bool seg_range(const DtkCompactArgs &A, uint32_t s, uint32_t len_of_d, SegRange &r) {
@@ -1560,17 +1542,38 @@ __device__ __forceinline__ bool seg_range(const DtkCompactArgs &A, uint32_t s, u
   return true;
 }
 
+// 32 bits of a bitmap starting at bit `bit` (the arrays are padded by two words)
+__device__ __forceinline__ uint32_t bits32(const uint32_t *__restrict__ b, uint32_t bit) {
+  const uint32_t w = bit >> 5, sh = bit & 31u;
+  const uint32_t lo = b[w], hi = b[w + 1];
+  return sh ? (lo >> sh) | (hi << (32u - sh)) : lo;
+}
+__device__ __forceinline__ uint32_t lowmask(uint32_t n) { return n >= 32u ? 0xFFFFFFFFu : (1u << n) - 1u; }
+
+// One wave per document (or per segment of a long one).
+// Light: tiles of 2048 cursor positions, 32 per lane -- the lane's word of every bitmap (token ends, token starts,
+// epsilon SentenceEnds, EOT calls; rune starts from k_symbolize's bitmap), rune counts by a wave scan.  A tile is
+// queued in eight steps of 256 positions (4 per lane, the words fetched from their lanes by shuffles): every
+// position that carries a call goes into a ring in LDS with its rune index and, for a token end, where the token
+// started (the highest START bit below it: in the same word or the one before; longer tokens search backwards).
+// Heavy: whenever 64 positions are queued (or at the end), lane i takes the i-th and everything NewTokenWriter
+// tracks (token_writer.go:38-42: posC, pos, sentB, sent) is recovered with ballots, popcounts of the lanes
+// below and a handful of shuffles; wave-uniform carries link the rounds.  Order of the calls at one position =
+// bit order of the queued flags.
 __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
-  __shared__ uint32_t qpos[CQ_CAP], qrn[CQ_CAP];
-  __shared__ uint16_t qfl[CQ_CAP];  // 8 event bits + 5 bits of token length
+  __shared__ uint32_t qpos[CQ_CAP], qrn[CQ_CAP], qst[CQ_CAP], qsr[CQ_CAP];
+  __shared__ uint8_t qfl[CQ_CAP];
   const bool seg_mode = A.seg_doc != nullptr;
   if (blockIdx.x >= (seg_mode ? A.n_segs : A.n_docs)) return;
   const uint32_t d = seg_mode ? A.seg_doc[blockIdx.x] : blockIdx.x;
   const uint64_t off = A.doc_off[d];
   const uint32_t len = (uint32_t)(A.doc_off[d + 1] - off);
-  const uint64_t evb = DTK_EV_BASE(off, d);
-  const uint8_t *__restrict__ evA = A.evA + evb;
-  const uint8_t *__restrict__ evB = A.evB + evb;
+  const uint32_t gb = (uint32_t)DTK_EV_BIT(off, d);
+  const uint32_t *__restrict__ bE = A.bits + (size_t)EVB_END * A.bit_words;
+  const uint32_t *__restrict__ bS = A.bits + (size_t)EVB_START * A.bit_words;
+  const uint32_t *__restrict__ bP = A.bits + (size_t)EVB_SEPS * A.bit_words;
+  const uint32_t *__restrict__ bT = A.bits + (size_t)EVB_TEOT * A.bit_words;
+  const uint32_t *__restrict__ bU = A.bits + (size_t)EVB_SEOT * A.bit_words;
   const uint8_t *__restrict__ txt = A.text + off;
   const bool nl_rule = (A.flags & 16u) != 0;  // NEWLINE_AFTER_EOT
   const bool is_matrix = A.kind == DTK_KIND_MATRIX;
@@ -1589,13 +1592,12 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
   const uint64_t tok_lim = A.tok_off[d + 1], sent_lim = A.sent_off[d + 1], text_lim = A.text_off[d + 1];
 
   // wave-uniform carries
-  uint32_t cR = 0;           // runes started before the light tile
+  uint32_t cR = 0;           // runes started before the tile
   uint32_t cTE = 0;          // token ends before the heavy round
   uint32_t cNE = 0, cNSev = 0;  // TextEnd / SentenceEnd calls before the round
   uint32_t cNSent = 0;       // sentence ints pushed before the round
   uint32_t cSEatEnd = 0, cEatEnd = 0;  // calls seen when the last token ended
   uint32_t cLastEndR = 0, cLastEndByte = 0;
-  uint32_t cStartP = 0, cStartR = 0;  // the last TOK_START seen: position, rune index
   int32_t cLastRend = 0;
   uint32_t cBase = 0;        // rune index that maps to offset 0 in the current text
   uint32_t cLastER = 0, cLastEByte = 0, cTokAtLastE = 0;
@@ -1628,7 +1630,7 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
       if (cTE > kf)
         cBase = kf == 0u ? (cHaveE ? cLastER : 0u)  // it was the document's first token
                          : cLastER + ((nl_rule && cLastEByte == '\n') ? 1u : 0u);
-      if (evA[sr.p0] & EV_TOK_END) {  // the rewind at p0 was a token flush: that token is "the last one"
+      if (bits32(bE, gb + sr.p0) & 1u) {  // the rewind at p0 was a token flush: that token is "the last one"
         cLastEndR = cR;
         cLastEndByte = (nl_rule && sr.p0 < len) ? txt[sr.p0] : 0u;
         cSEatEnd = cNSev + cNE; cEatEnd = cNE;
@@ -1638,242 +1640,265 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
   }
 
   const uint32_t n_pos = sr.p1 + 1u;  // cursor positions p0..p1
-  // bytes of a dword at positions q..q+3 that lie in [a, b]
-  auto in_range = [](uint32_t q, uint32_t a, uint32_t b) -> uint32_t {
-    if (q + 3u < a || q > b) return 0u;
-    const uint32_t first = a > q ? a - q : 0u, last = b - q < 3u ? b - q : 3u;
-    return (0xFFFFFFFFu >> (8u * (3u - last))) & (0xFFFFFFFFu << (8u * first));
-  };
-  for (uint32_t base = sr.p0 & ~3u; base < n_pos; base += 4u * WAVE) {
-    // ---- light phase
-    const uint32_t P0 = base + lane * 4u;
-    uint32_t fw = 0, lw = 0, rsn = 0;  // 4 event bytes (one per position), token length fields, rune-start nibble
-    if (P0 < n_pos) {
-      // DTK_EV_BASE is 4-byte aligned and the arrays are padded: whole dwords are readable,
-      // bytes behind position `len` are zero (cleared, never written)
-      uint32_t fa = *reinterpret_cast<const uint32_t *>(evA + P0);
-      uint32_t fb = *reinterpret_cast<const uint32_t *>(evB + P0);
-      if (seg_mode) {  // closing events in (p0, p1], opening events in [p0, p1) or, at the end, [p0, p1]
-        fa &= in_range(P0, sr.p0 + 1u, sr.p1);
-        fb &= sr.last ? in_range(P0, sr.p0, sr.p1) : (sr.p1 > sr.p0 ? in_range(P0, sr.p0, sr.p1 - 1u) : 0u);
+  // what the tile before left for the first lane: the START and rune-start words of the 32 positions before
+  // the tile, and the rune index at their first position (a segment starts at a rewind: no token spans it)
+  uint32_t pS_in = 0, pR_in = 0, pRb_in = cR;
+  for (uint32_t T0 = sr.p0; T0 < n_pos; T0 += 32u * WAVE) {
+    // ---- the lane's words: positions q0 .. q0 + 31
+    const uint32_t q0 = T0 + 32u * lane;
+    uint32_t wE = 0, wS = 0, wP = 0, wT = 0, wU = 0, wR = 0;
+    if (q0 < n_pos) {
+      const uint32_t valid = lowmask(n_pos - q0);
+      wE = bits32(bE, gb + q0) & valid; wS = bits32(bS, gb + q0) & valid; wP = bits32(bP, gb + q0) & valid;
+      wT = bits32(bT, gb + q0) & valid; wU = bits32(bU, gb + q0) & valid;
+      if (q0 < len) wR = bits32(A.rs_bits, (uint32_t)off + q0) & lowmask(len - q0);  // rune starts: bit = input byte
+      if (seg_mode) {  // closing kinds in (p0, p1], opening kinds in [p0, p1) or, at the end, [p0, p1]
+        if (q0 == sr.p0) { wE &= ~1u; wT &= ~1u; wU &= ~1u; }
+        if (!sr.last && sr.p1 >= q0 && sr.p1 - q0 < 32u) { wS &= ~(1u << (sr.p1 - q0)); wP &= ~(1u << (sr.p1 - q0)); }
       }
-      fw = (fa & 0x07070707u) | fb;
-      lw = (fa >> EV_LEN_SHIFT) & 0x1F1F1F1Fu;
-      const uint32_t left = n_pos - P0;  // positions of mine that exist
-      if (left < 4u) fw &= (1u << (8u * left)) - 1u;
-      // rune starts of my 4 positions from the bitmap (bit = input byte index)
-      const uint64_t g0 = off + P0;
-      const uint32_t *wp = A.rs_bits + (g0 >> 5);
-      const uint64_t two = (uint64_t)wp[0] | ((uint64_t)wp[1] << 32);
-      const uint32_t have = len > P0 ? (len - P0 >= 4u ? 4u : len - P0) : 0u;
-      rsn = (uint32_t)(two >> (g0 & 31u)) & ((1u << have) - 1u);
-      if (P0 < sr.p0) rsn &= ~((1u << (sr.p0 - P0)) - 1u);  // runes before p0 are in the carry
     }
-    const uint32_t evn = ((fw & 0xFFu) ? 1u : 0u) | ((fw & 0xFF00u) ? 2u : 0u) | ((fw & 0xFF0000u) ? 4u : 0u) |
-                         ((fw & 0xFF000000u) ? 8u : 0u);
-    uint32_t tot;
-    const uint32_t ex = wave_excl_scan((uint32_t)__popc(evn) | ((uint32_t)__popc(rsn) << 16), tot);
-    uint32_t slot = qhead + qn + (ex & 0xFFFFu);
-    const uint32_t Rl = cR + (ex >> 16);
+    uint32_t tileR;
+    const uint32_t rB = cR + wave_excl_scan((uint32_t)__popc(wR), tileR);  // rune index at q0
+    // the words of the 32 positions before mine
+    uint32_t pS = __shfl_up(wS, 1), pR = __shfl_up(wR, 1), pRb = __shfl_up(rB, 1);
+    if (lane == 0) { pS = pS_in; pR = pR_in; pRb = pRb_in; }
+    const bool any_eot = __ballot((wT | wU) != 0u) != 0ull;  // wave-uniform: most tiles hold no EOT
+    const bool last_tile = T0 + 32u * WAVE >= n_pos;
+
+    for (uint32_t step = 0; step < 8u; step++) {
+      const uint32_t S0 = T0 + 256u * step;  // first position of the step (wave-uniform)
+      if (S0 >= n_pos) break;
+      // ---- light: my 4 positions P0 .. P0 + 3 live in the word of lane `src`, bits ns .. ns + 3
+      const uint32_t src = 8u * step + (lane >> 3), ns = (lane & 7u) * 4u;
+      const uint32_t P0 = S0 + 4u * lane;
+      const uint32_t xE = __shfl(wE, src), xP = __shfl(wP, src), xS = __shfl(wS, src), xR = __shfl(wR, src);
+      const uint32_t xRb = __shfl(rB, src), yS = __shfl(pS, src), yR = __shfl(pR, src), yRb = __shfl(pRb, src);
+      uint32_t nE = (xE >> ns) & 15u, nP = (xP >> ns) & 15u, nT = 0, nU = 0;
+      if (any_eot) { nT = (__shfl(wT, src) >> ns) & 15u; nU = (__shfl(wU, src) >> ns) & 15u; }
+      const uint32_t evn = nE | nP | nT | nU;  // positions of mine that carry a call
+      uint32_t tot;
+      const uint32_t ex = wave_excl_scan((uint32_t)__popc(evn), tot);
+      uint32_t slot = qhead + qn + ex;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      if (evn & (1u << j)) {
-        const uint32_t at = slot & (CQ_CAP - 1u);
-        qpos[at] = P0 + j;
-        qfl[at] = (uint16_t)(((fw >> (8 * j)) & 0xFFu) | (((lw >> (8 * j)) & 0x1Fu) << 8));
-        qrn[at] = Rl + (uint32_t)__popc(rsn & ((1u << j) - 1u));
-        slot++;
+      for (uint32_t j = 0; j < 4u; j++) {
+        if (evn & (1u << j)) {
+          const uint32_t b = ns + j, at = slot & (CQ_CAP - 1u);
+          const uint32_t R = xRb + (uint32_t)__popc(xR & lowmask(b));
+          qpos[at] = P0 + j;
+          qrn[at] = R;
+          qfl[at] = (uint8_t)(((nU >> j) & 1u) * EV_S_EOT | ((nT >> j) & 1u) * EV_E_EOT | ((nE >> j) & 1u) * EV_TOK_END |
+                              ((nP >> j) & 1u) * EV_S_EPS);
+          if (nE & (1u << j)) {
+            // the token's first byte: the highest START bit below this position
+            uint32_t sp, sr_;
+            const uint32_t m = xS & lowmask(b);
+            if (m) {
+              const uint32_t sb = 31u - (uint32_t)__clz((int)m);
+              sp = P0 + j - (b - sb);
+              sr_ = xRb + (uint32_t)__popc(xR & lowmask(sb));
+            } else if (yS) {
+              const uint32_t sb = 31u - (uint32_t)__clz((int)yS);
+              sp = P0 + j - b - 32u + sb;
+              sr_ = yRb + (uint32_t)__popc(yR & lowmask(sb));
+            } else {  // a token of more than 32 bytes: search backwards (rare)
+              const uint32_t ws = P0 + j - b;  // first position of my word; the 32 before it hold no START
+              uint32_t q = ws >= sr.p0 + 32u ? ws - 32u : sr.p0;
+              uint32_t w = 0;
+              while (!w && q > sr.p0) {
+                const uint32_t n = q - sr.p0 < 32u ? q - sr.p0 : 32u;
+                q -= n;
+                w = bits32(bS, gb + q) & lowmask(n);
+              }
+              sp = w ? q + 31u - (uint32_t)__clz((int)w) : sr.p0;
+              sr_ = R;
+              for (uint32_t z = sp; z < P0 + j; z += 32u)  // rune starts in [sp, position)
+                sr_ -= (uint32_t)__popc(bits32(A.rs_bits, (uint32_t)off + z) & lowmask(P0 + j - z));
+            }
+            qst[at] = sp; qsr[at] = sr_;
+          }
+          slot++;
+        }
       }
-    }
-    qn += tot & 0xFFFFu;
-    cR += tot >> 16;
-    __syncthreads();
-    const bool last_tile = base + 4u * WAVE >= n_pos;
-
-    // ---- heavy phase
-    while (qn >= WAVE || (last_tile && qn > 0)) {
-    const uint32_t take = qn < WAVE ? qn : WAVE;
-    uint32_t P = 0, f = 0, R = 0, tb = 0;
-    if (lane < take) {
-      const uint32_t at = (qhead + lane) & (CQ_CAP - 1u);
-      P = qpos[at]; f = qfl[at]; R = qrn[at];
-      // byte behind a token / an EOT: only the NEWLINE_AFTER_EOT rule looks at it (token_writer.go:66-68)
-      if (nl_rule && (f & (EV_TOK_END | EV_E_EOT)) && P < len) tb = txt[P];
-    }
-    qhead += take;
-    qn -= take;
-    const unsigned long long mEND = __ballot(f & EV_TOK_END);
-    const unsigned long long mEEOT = __ballot(f & EV_E_EOT);
-    const unsigned long long mEEOF = __ballot(f & EV_E_EOF);
-    const unsigned long long mS1 = __ballot(f & EV_S_EOT);
-    const unsigned long long mS2 = __ballot(f & EV_S_EPS);
-    const unsigned long long mS3 = __ballot(f & EV_S_EPS2);
-    const unsigned long long mS4 = __ballot(f & EV_S_EOF);
-
-    // Order of the calls at one position (bit order): S_EOT, E_EOT, TOK_END,
-    // S_EPS, S_EPS2, S_EOF, E_EOF.
-    const uint32_t te = cTE + popc(mEND & lt);   // tokens ended at lower positions
-    const bool isEnd = (f & EV_TOK_END) != 0;
-    const bool hasEEOT = (f & EV_E_EOT) != 0;
-    const uint32_t s1 = (f & EV_S_EOT) ? 1u : 0u;
-    const uint32_t sLate = popc((unsigned long long)(f & (EV_S_EPS | EV_S_EPS2 | EV_S_EOF)));
-    // TextEnd / SentenceEnd calls fired before this lane's TOK_END (own EOT pair included)
-    const uint32_t eBeforeEnd = cNE + popc(mEEOT & lt) + popc(mEEOF & lt) + (hasEEOT ? 1u : 0u);
-    const uint32_t sBeforeEnd =
-        cNSev + popc(mS1 & lt) + popc(mS2 & lt) + popc(mS3 & lt) + popc(mS4 & lt) + s1;
-    const uint32_t tokLate = te + (isEnd ? 1u : 0u);  // tokens ended before this lane's late calls
-
-    // previous token end (strictly below this lane)
-    const unsigned long long mPrevEnd = mEND & lt;
-    const bool havePrev = mPrevEnd != 0ull;
-    const int jp = havePrev ? highest(mPrevEnd) : 0;
-    const uint32_t seAtPrev_t = __shfl(eBeforeEnd + sBeforeEnd, jp);
-    const uint32_t eAtPrev_t = __shfl(eBeforeEnd, jp);
-    const uint32_t RatPrev_t = __shfl(R, jp);
-    const uint32_t byteAtPrev_t = nl_rule ? __shfl(tb, jp) : 0u;
-    const uint32_t seAtPrev = havePrev ? seAtPrev_t : cSEatEnd;
-    const uint32_t eAtPrev = havePrev ? eAtPrev_t : cEatEnd;
-    const uint32_t RatPrev = havePrev ? RatPrev_t : cLastEndR;
-    const uint32_t byteAtPrev = havePrev ? byteAtPrev_t : cLastEndByte;
-
-    const uint32_t k = te;  // index of the token that ends here
-    const bool text_first = isEnd && (k == 0 || eBeforeEnd > eAtPrev);
-    const bool sent_first = isEnd && (k == 0 || (eBeforeEnd + sBeforeEnd) > seAtPrev);
-
-    // last E_EOT strictly below this lane
-    const unsigned long long mPrevE = mEEOT & lt;
-    const bool haveE = mPrevE != 0ull;
-    const int je = haveE ? highest(mPrevE) : 0;
-    uint32_t RatE_t = 0, byteAtE_t = 0, tokAtE_t = 0;
-    if (mEEOT) {  // wave-uniform: most rounds hold no EOT
-      RatE_t = __shfl(R, je);
-      byteAtE_t = __shfl(tb, je);
-      tokAtE_t = __shfl(te, je);  // an E_EOT precedes a token end at its own position
-    }
-    const uint32_t RatE = haveE ? RatE_t : cLastER;
-    const uint32_t byteAtE = haveE ? byteAtE_t : cLastEByte;
-    const uint32_t tokAtPrevE = haveE ? tokAtE_t : cTokAtLastE;
-    const bool anyE = haveE || cHaveE;
-
-    // where the token that ends here started: its length field, or -- saturated field -- the last
-    // TOK_START strictly below this position (long tokens' starts and ends alternate); the rune
-    // length is the number of rune starts in between (bitmap for the short ones)
-    const uint32_t lenf = (f >> 8) & 0x1Fu;
-    const unsigned long long mSTART = __ballot(f & EV_TOK_START);
-    const unsigned long long mPrevStart = mSTART & lt;
-    const int js = mPrevStart ? highest(mPrevStart) : 0;
-    uint32_t startP_t = 0, startR_t = 0;
-    if (mSTART) { startP_t = __shfl(P, js); startR_t = __shfl(R, js); }  // wave-uniform: tokens of 31 bytes and more
-    uint32_t startP = mPrevStart ? startP_t : cStartP;
-    uint32_t startR = mPrevStart ? startR_t : cStartR;
-    if (isEnd && lenf < EV_LEN_LONG) {
-      startP = P - lenf;
-      const uint64_t g = off + startP;
-      const uint32_t *wp = A.rs_bits + (g >> 5);
-      const uint64_t two = (uint64_t)wp[0] | ((uint64_t)wp[1] << 32);
-      startR = R - (uint32_t)__popcll((two >> (g & 31u)) & ((1ull << lenf) - 1ull));
-    }
-    // rune index that counts as offset 0 for the text this token opens
-    // (token_writer.go:66-81: posC restarts at 0; the offset handed to Token is
-    // counted from the start of the window, which the matrix rewinds to the rune
-    // after EOT (matrix.go:601) and the double array only at token flushes).
-    uint32_t base_mine;
-    if (k == 0) {
-      base_mine = (is_matrix && anyE) ? RatE : 0u;
-    } else if (is_matrix) {
-      base_mine = RatE + ((nl_rule && byteAtE == '\n') ? 1u : 0u);
-    } else {
-      base_mine = RatPrev + ((nl_rule && byteAtPrev == '\n') ? 1u : 0u);
-    }
-    const unsigned long long mTF = __ballot(text_first);
-    const unsigned long long mPrevTF = mTF & lt;
-    const int jt = mPrevTF ? highest(mPrevTF) : 0;
-    const uint32_t baseFrom_t = __shfl(base_mine, jt);
-    const uint32_t tbase = text_first ? base_mine : (mPrevTF ? baseFrom_t : cBase);
-    const int32_t rend = (int32_t)(R - tbase);
-    const int32_t rstart = rend - (int32_t)(R - startR);
-
-    // end offset of the last token below this lane / at or below it
-    const int32_t rendPrev_t = __shfl(rend, jp);
-    const int32_t rendBelow = havePrev ? rendPrev_t : cLastRend;
-    const int32_t rendLate = isEnd ? rend : rendBelow;
-
-    // SentenceEnd / TextEnd with no token in the current text (reference panics)
-    const bool emptyEarly = te == tokAtPrevE;                       // for S_EOT, E_EOT
-    const bool emptyLate = hasEEOT ? !isEnd : (tokLate == tokAtPrevE);  // for S_EPS.., E_EOF
-    const uint32_t s1_valid = emptyEarly ? 0u : s1;
-    const uint32_t sLate_valid = emptyLate ? 0u : sLate;
-    if ((s1 && emptyEarly) || (hasEEOT && emptyEarly) || (sLate && emptyLate) ||
-        ((f & EV_E_EOF) && emptyLate))
-      status |= ST_EMPTY_TEXT;
-
-    const uint32_t c = s1_valid + (sent_first ? 1u : 0u) + sLate_valid;
-    uint32_t cTotal;
-    const uint32_t excl = wave_excl_scan(c, cTotal);
-
-    {
-      if (isEnd && tok_base + k < tok_lim) {
-        A.tok_bstart[tok_base + k] = startP;
-        A.tok_bend[tok_base + k] = P;
-        A.tok_rstart[tok_base + k] = rstart;
-        A.tok_rend[tok_base + k] = rend;
-        if (A.tok_sbefore) A.tok_sbefore[tok_base + k] = sBeforeEnd;  // SentenceEnd calls before this Token call
+      qn += tot;
+      __syncthreads();
+      bool drain = last_tile && (step == 7u || S0 + 256u >= n_pos);
+      if (drain && sr.last) {
+        // the final SentenceEnd / TextEnd of the document (matrix.go:683-691): queued behind everything
+        const uint32_t tw = A.doc_tail[d];
+        if (tw & 3u) {
+          if (lane == 0) {
+            const uint32_t at = (qhead + qn) & (CQ_CAP - 1u);
+            qpos[at] = tw >> 2; qrn[at] = cR + tileR;
+            qfl[at] = (uint8_t)(((tw & DTK_TAIL_S) ? EV_S_EOF : 0u) | ((tw & DTK_TAIL_E) ? EV_E_EOF : 0u));
+          }
+          qn += 1u;
+          __syncthreads();
+        }
       }
-      uint64_t si = sent_base + cNSent + excl;
-      if (si + c <= sent_lim) {
-        if (s1_valid) A.sent[si++] = rendBelow;         // token_writer.go:108
-        if (sent_first) A.sent[si++] = rstart;          // token_writer.go:76-79
-        for (uint32_t q = 0; q < sLate_valid; q++) A.sent[si++] = rendLate;
-      } else if (c) {
-        status |= ST_INTERNAL;
-      }
-      if (hasEEOT) {
-        const uint64_t ti = text_base + eBeforeEnd - 1u;
-        if (ti < text_lim) {
-          A.text_tok_end[ti] = te;
-          A.text_sent_end[ti] = cNSent + excl + s1_valid;
-          if (A.text_s_end) A.text_s_end[ti] = sBeforeEnd;  // SentenceEnd calls before this TextEnd call
-        } else status |= ST_INTERNAL;
-      }
-      if (f & EV_E_EOF) {
-        const uint64_t ti = text_base + eBeforeEnd;
-        if (ti < text_lim) {
-          A.text_tok_end[ti] = tokLate;
-          A.text_sent_end[ti] = cNSent + excl + c;
-          if (A.text_s_end) A.text_s_end[ti] = sBeforeEnd + sLate;
-        } else status |= ST_INTERNAL;
-      }
-      if (isEnd && tok_base + k >= tok_lim) status |= ST_INTERNAL;
-    }
 
-    // carries for the next tile
-    if (mEND) {
-      const int jl = highest(mEND);
-      cSEatEnd = __shfl(eBeforeEnd + sBeforeEnd, jl);
-      cEatEnd = __shfl(eBeforeEnd, jl);
-      cLastEndR = __shfl(R, jl);
-      cLastEndByte = nl_rule ? __shfl(tb, jl) : 0u;
-      cLastRend = __shfl(rend, jl);
-      cBase = __shfl(tbase, jl);
-    }
-    if (mSTART) {
-      const int jl = highest(mSTART);
-      cStartP = __shfl(P, jl);
-      cStartR = __shfl(R, jl);
-    }
-    if (mEEOT) {
-      const int jl = highest(mEEOT);
-      cLastER = __shfl(R, jl);
-      cLastEByte = __shfl(tb, jl);
-      cTokAtLastE = __shfl(te, jl);
-      cHaveE = true;
-    }
-    cTE += popc(mEND);
-    cNE += popc(mEEOT) + popc(mEEOF);
-    cNSev += popc(mS1) + popc(mS2) + popc(mS3) + popc(mS4);
-    cNSent += cTotal;
-    }  // heavy rounds
-    __syncthreads();
+      // ---- heavy
+      while (qn >= WAVE || (drain && qn > 0)) {
+      const uint32_t take = qn < WAVE ? qn : WAVE;
+      uint32_t P = 0, f = 0, R = 0, tb = 0, startP = 0, startR = 0;
+      if (lane < take) {
+        const uint32_t at = (qhead + lane) & (CQ_CAP - 1u);
+        P = qpos[at]; f = qfl[at]; R = qrn[at];
+        if (f & EV_TOK_END) { startP = qst[at]; startR = qsr[at]; }
+        // byte behind a token / an EOT: only the NEWLINE_AFTER_EOT rule looks at it (token_writer.go:66-68)
+        if (nl_rule && (f & (EV_TOK_END | EV_E_EOT)) && P < len) tb = txt[P];
+      }
+      qhead += take;
+      qn -= take;
+      const unsigned long long mEND = __ballot(f & EV_TOK_END);
+      const unsigned long long mEEOT = __ballot(f & EV_E_EOT);
+      const unsigned long long mEEOF = __ballot(f & EV_E_EOF);
+      const unsigned long long mS1 = __ballot(f & EV_S_EOT);
+      const unsigned long long mS2 = __ballot(f & EV_S_EPS);
+      const unsigned long long mS4 = __ballot(f & EV_S_EOF);
+
+      // Order of the calls at one position (bit order): S_EOT, E_EOT, TOK_END, S_EPS, S_EOF, E_EOF.
+      const uint32_t te = cTE + popc(mEND & lt);   // tokens ended at lower positions
+      const bool isEnd = (f & EV_TOK_END) != 0;
+      const bool hasEEOT = (f & EV_E_EOT) != 0;
+      const uint32_t s1 = (f & EV_S_EOT) ? 1u : 0u;
+      const uint32_t sLate = popc((unsigned long long)(f & (EV_S_EPS | EV_S_EOF)));
+      // TextEnd / SentenceEnd calls fired before this lane's TOK_END (own EOT pair included)
+      const uint32_t eBeforeEnd = cNE + popc(mEEOT & lt) + popc(mEEOF & lt) + (hasEEOT ? 1u : 0u);
+      const uint32_t sBeforeEnd = cNSev + popc(mS1 & lt) + popc(mS2 & lt) + popc(mS4 & lt) + s1;
+      const uint32_t tokLate = te + (isEnd ? 1u : 0u);  // tokens ended before this lane's late calls
+
+      // previous token end (strictly below this lane)
+      const unsigned long long mPrevEnd = mEND & lt;
+      const bool havePrev = mPrevEnd != 0ull;
+      const int jp = havePrev ? highest(mPrevEnd) : 0;
+      const uint32_t seAtPrev_t = __shfl(eBeforeEnd + sBeforeEnd, jp);
+      const uint32_t eAtPrev_t = __shfl(eBeforeEnd, jp);
+      const uint32_t RatPrev_t = __shfl(R, jp);
+      const uint32_t byteAtPrev_t = nl_rule ? __shfl(tb, jp) : 0u;
+      const uint32_t seAtPrev = havePrev ? seAtPrev_t : cSEatEnd;
+      const uint32_t eAtPrev = havePrev ? eAtPrev_t : cEatEnd;
+      const uint32_t RatPrev = havePrev ? RatPrev_t : cLastEndR;
+      const uint32_t byteAtPrev = havePrev ? byteAtPrev_t : cLastEndByte;
+
+      const uint32_t k = te;  // index of the token that ends here
+      const bool text_first = isEnd && (k == 0 || eBeforeEnd > eAtPrev);
+      const bool sent_first = isEnd && (k == 0 || (eBeforeEnd + sBeforeEnd) > seAtPrev);
+
+      // last E_EOT strictly below this lane
+      const unsigned long long mPrevE = mEEOT & lt;
+      const bool haveE = mPrevE != 0ull;
+      const int je = haveE ? highest(mPrevE) : 0;
+      uint32_t RatE_t = 0, byteAtE_t = 0, tokAtE_t = 0;
+      if (mEEOT) {  // wave-uniform: most rounds hold no EOT
+        RatE_t = __shfl(R, je);
+        byteAtE_t = __shfl(tb, je);
+        tokAtE_t = __shfl(te, je);  // an E_EOT precedes a token end at its own position
+      }
+      const uint32_t RatE = haveE ? RatE_t : cLastER;
+      const uint32_t byteAtE = haveE ? byteAtE_t : cLastEByte;
+      const uint32_t tokAtPrevE = haveE ? tokAtE_t : cTokAtLastE;
+      const bool anyE = haveE || cHaveE;
+
+      // rune index that counts as offset 0 for the text this token opens
+      // (token_writer.go:66-81: posC restarts at 0; the offset handed to Token is
+      // counted from the start of the window, which the matrix rewinds to the rune
+      // after EOT (matrix.go:601) and the double array only at token flushes).
+      uint32_t base_mine;
+      if (k == 0) {
+        base_mine = (is_matrix && anyE) ? RatE : 0u;
+      } else if (is_matrix) {
+        base_mine = RatE + ((nl_rule && byteAtE == '\n') ? 1u : 0u);
+      } else {
+        base_mine = RatPrev + ((nl_rule && byteAtPrev == '\n') ? 1u : 0u);
+      }
+      const unsigned long long mTF = __ballot(text_first);
+      const unsigned long long mPrevTF = mTF & lt;
+      const int jt = mPrevTF ? highest(mPrevTF) : 0;
+      const uint32_t baseFrom_t = __shfl(base_mine, jt);
+      const uint32_t tbase = text_first ? base_mine : (mPrevTF ? baseFrom_t : cBase);
+      const int32_t rend = (int32_t)(R - tbase);
+      const int32_t rstart = rend - (int32_t)(R - startR);
+
+      // end offset of the last token below this lane / at or below it
+      const int32_t rendPrev_t = __shfl(rend, jp);
+      const int32_t rendBelow = havePrev ? rendPrev_t : cLastRend;
+      const int32_t rendLate = isEnd ? rend : rendBelow;
+
+      // SentenceEnd / TextEnd with no token in the current text (reference panics)
+      const bool emptyEarly = te == tokAtPrevE;                       // for S_EOT, E_EOT
+      const bool emptyLate = hasEEOT ? !isEnd : (tokLate == tokAtPrevE);  // for S_EPS.., E_EOF
+      const uint32_t s1_valid = emptyEarly ? 0u : s1;
+      const uint32_t sLate_valid = emptyLate ? 0u : sLate;
+      if ((s1 && emptyEarly) || (hasEEOT && emptyEarly) || (sLate && emptyLate) ||
+          ((f & EV_E_EOF) && emptyLate))
+        status |= ST_EMPTY_TEXT;
+
+      const uint32_t c = s1_valid + (sent_first ? 1u : 0u) + sLate_valid;
+      uint32_t cTotal;
+      const uint32_t excl = wave_excl_scan(c, cTotal);
+
+      {
+        if (isEnd && tok_base + k < tok_lim) {
+          A.tok_bstart[tok_base + k] = startP;
+          A.tok_bend[tok_base + k] = P;
+          A.tok_rstart[tok_base + k] = rstart;
+          A.tok_rend[tok_base + k] = rend;
+          if (A.tok_sbefore) A.tok_sbefore[tok_base + k] = sBeforeEnd;  // SentenceEnd calls before this Token call
+        }
+        uint64_t si = sent_base + cNSent + excl;
+        if (si + c <= sent_lim) {
+          if (s1_valid) A.sent[si++] = rendBelow;         // token_writer.go:108
+          if (sent_first) A.sent[si++] = rstart;          // token_writer.go:76-79
+          for (uint32_t q = 0; q < sLate_valid; q++) A.sent[si++] = rendLate;
+        } else if (c) {
+          status |= ST_INTERNAL;
+        }
+        if (hasEEOT) {
+          const uint64_t ti = text_base + eBeforeEnd - 1u;
+          if (ti < text_lim) {
+            A.text_tok_end[ti] = te;
+            A.text_sent_end[ti] = cNSent + excl + s1_valid;
+            if (A.text_s_end) A.text_s_end[ti] = sBeforeEnd;  // SentenceEnd calls before this TextEnd call
+          } else status |= ST_INTERNAL;
+        }
+        if (f & EV_E_EOF) {
+          const uint64_t ti = text_base + eBeforeEnd;
+          if (ti < text_lim) {
+            A.text_tok_end[ti] = tokLate;
+            A.text_sent_end[ti] = cNSent + excl + c;
+            if (A.text_s_end) A.text_s_end[ti] = sBeforeEnd + sLate;
+          } else status |= ST_INTERNAL;
+        }
+        if (isEnd && tok_base + k >= tok_lim) status |= ST_INTERNAL;
+      }
+
+      // carries for the next round
+      if (mEND) {
+        const int jl = highest(mEND);
+        cSEatEnd = __shfl(eBeforeEnd + sBeforeEnd, jl);
+        cEatEnd = __shfl(eBeforeEnd, jl);
+        cLastEndR = __shfl(R, jl);
+        cLastEndByte = nl_rule ? __shfl(tb, jl) : 0u;
+        cLastRend = __shfl(rend, jl);
+        cBase = __shfl(tbase, jl);
+      }
+      if (mEEOT) {
+        const int jl = highest(mEEOT);
+        cLastER = __shfl(R, jl);
+        cLastEByte = __shfl(tb, jl);
+        cTokAtLastE = __shfl(te, jl);
+        cHaveE = true;
+      }
+      cTE += popc(mEND);
+      cNE += popc(mEEOT) + popc(mEEOF);
+      cNSev += popc(mS1) + popc(mS2) + popc(mS4);
+      cNSent += cTotal;
+      }  // heavy rounds
+      __syncthreads();
+    }  // steps of the tile
+    // hand the last lane's words to the next tile's first lane
+    pS_in = __shfl(wS, WAVE - 1); pR_in = __shfl(wR, WAVE - 1); pRb_in = __shfl(rB, WAVE - 1);
+    cR += tileR;
   }
 
   // the walk's counts sized the rows: they must agree with what was written here
@@ -1882,9 +1907,8 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
   for (int o = 32; o > 0; o >>= 1) sred |= __shfl_down(sred, o);
   sred = __shfl(sred, 0);
   if (lane == 0) {
-    // The walk's counts sized the rows.  If the position-indexed bytes do not add up to them, two calls fell on one
-    // byte: the double array fired one EOT twice from two different lanes (the lane that revisits it does not know
-    // that its predecessor fired it, so the walk's own test misses it).  The exact pass decides: it walks the
+    // The walk's counts sized the rows.  If the bitmaps do not add up to them, two calls fell on one bit: the
+    // double array fired one EOT twice from two different lanes, say.  The exact pass decides: it walks the
     // document in call order and reports ST_INTERNAL itself if its calls do not fill the rows either.
     if (sr.last && (tok_base + cTE != tok_lim || sent_base + cNSent != sent_lim || text_base + cNE != text_lim))
       sred |= ST_INTERNAL;
@@ -2143,15 +2167,9 @@ extern "C" int dtk_launch_spec(const DtkTableDev *tab, const DtkWalkArgs *args, 
     case 6:  // first pass: start records and chunk walk in one launch
       return with_trans(tab, [&](auto tr, auto is_matrix) {
         using TR = decltype(tr);
-        if constexpr (TR::LEAN) {
-          if (spec->ev_lists) {
-            hipLaunchKernelGGL((k_spec_both<TR, decltype(is_matrix)::value, true>), dim3(lane_blocks), dim3(WAVE), 0,
-                               s, tr, *args, *spec, tab->epsilon, tab->unknown, tab->identity);
-            return;
-          }
-        }
-        hipLaunchKernelGGL((k_spec_both<TR, decltype(is_matrix)::value, false>), dim3(lane_blocks), dim3(WAVE), 0, s,
-                           tr, *args, *spec, tab->epsilon, tab->unknown, tab->identity);
+        hipLaunchKernelGGL((k_spec_both<TR, decltype(is_matrix)::value>), dim3(lane_blocks), dim3(WAVE),
+                           3u * spec->lds_words * sizeof(uint32_t), s, tr, *args, *spec, tab->epsilon, tab->unknown,
+                           tab->identity);
       });
     case 1:
       hipLaunchKernelGGL(k_spec_link, dim3(lane_blocks256), dim3(256), 0, s, *spec);
@@ -2159,15 +2177,9 @@ extern "C" int dtk_launch_spec(const DtkTableDev *tab, const DtkWalkArgs *args, 
     case 2:
       return with_trans(tab, [&](auto tr, auto is_matrix) {
         using TR = decltype(tr);
-        if constexpr (TR::LEAN) {
-          if (spec->ev_lists) {
-            hipLaunchKernelGGL((k_spec_walk<TR, decltype(is_matrix)::value, true>), dim3(lane_blocks), dim3(WAVE), 0,
-                               s, tr, *args, *spec, tab->epsilon, tab->unknown, tab->identity);
-            return;
-          }
-        }
-        hipLaunchKernelGGL((k_spec_walk<TR, decltype(is_matrix)::value, false>), dim3(lane_blocks), dim3(WAVE), 0, s,
-                           tr, *args, *spec, tab->epsilon, tab->unknown, tab->identity);
+        hipLaunchKernelGGL((k_spec_walk<TR, decltype(is_matrix)::value>), dim3(lane_blocks), dim3(WAVE),
+                           3u * spec->lds_words * sizeof(uint32_t), s, tr, *args, *spec, tab->epsilon, tab->unknown,
+                           tab->identity);
       });
     case 3:
       hipLaunchKernelGGL(k_spec_verify, dim3(lane_blocks256), dim3(256), 0, s, *args, *spec, cmp_mask);
@@ -2183,11 +2195,9 @@ extern "C" int dtk_launch_spec(const DtkTableDev *tab, const DtkWalkArgs *args, 
   return -1;
 }
 
-extern "C" int dtk_launch_redo_clear(const DtkWalkArgs *args, const DtkSpecArgs *spec, const uint32_t *blk_doc,
-                                     uint64_t total, void *stream) {
-  if (total == 0) return 0;
-  const uint32_t blocks = (uint32_t)((total + DTK_SYM_BLOCK_BYTES - 1) / DTK_SYM_BLOCK_BYTES);
-  hipLaunchKernelGGL(k_redo_clear, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *args, *spec, blk_doc, total);
+extern "C" int dtk_launch_redo_clear(const DtkWalkArgs *args, const DtkSpecArgs *spec, void *stream) {
+  if (args->bit_words == 0) return 0;
+  hipLaunchKernelGGL(k_redo_clear, dim3((args->bit_words + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, *args, *spec);
   return (int)hipGetLastError();
 }
 

@@ -13,7 +13,9 @@ TOKENS, SENTENCES, TOKEN_POS, SENTENCE_POS, NEWLINE_AFTER_EOT = 1, 2, 4, 8, 16
 SIMPLE = TOKENS | SENTENCES
 OFFSETS_ONLY = 256   # Batch.run only: skip the device renderer's bookkeeping
 
-EV_S_EOT, EV_E_EOT, EV_TOK_END, EV_S_EPS, EV_S_EPS2, EV_S_EOF, EV_E_EOF = 1, 2, 4, 8, 16, 32, 64
+# calls at one cursor position, in the order they fire (flag byte of event_bytes(); datok_gpu.h DTK_EVB_* / DTK_TAIL_*)
+EV_S_EOT, EV_E_EOT, EV_TOK_END, EV_S_EPS, EV_S_EOF, EV_E_EOF = 1, 2, 4, 8, 32, 64
+EVB_END, EVB_START, EVB_SEPS, EVB_TEOT, EVB_SEOT = 0, 1, 2, 3, 4
 
 
 # ------------------------------------------------------------------ UTF-8 (Go)
@@ -131,8 +133,24 @@ def new_token_writer(w, flags) -> TokenWriter:
     return tw
 
 
+def event_bytes(ev_bits, doc_off_d, d, n, tail):
+    """One flag byte per cursor position 0..n of document d (EV_* bits, bit order = call order) from the event
+    bitmaps of a host dtk_result_view (ev_bits: uint32[kinds, words]) and the document's tail word."""
+    g0 = int(doc_off_d) + int(d)
+    w0, w1 = g0 >> 5, (g0 + n + 32) >> 5
+    out = np.zeros(n + 1, dtype=np.uint8)
+    for kind, flag in ((EVB_SEOT, EV_S_EOT), (EVB_TEOT, EV_E_EOT), (EVB_END, EV_TOK_END), (EVB_SEPS, EV_S_EPS)):
+        words = np.ascontiguousarray(ev_bits[kind, w0:w1 + 1])
+        bits = np.unpackbits(words.view(np.uint8), bitorder="little")[g0 - 32 * w0: g0 - 32 * w0 + n + 1]
+        out |= bits * np.uint8(flag)
+    tail = int(tail)
+    if tail & 3:
+        out[min(tail >> 2, n)] |= (EV_S_EOF if tail & 1 else 0) | (EV_E_EOF if tail & 2 else 0)
+    return out
+
+
 def replay(is_matrix, text: bytes, events, tok_bstart, tw: TokenWriter):
-    """Feeds one document's event bytes to the closures in reference call order.
+    """Feeds one document's events (event_bytes()) to the closures in reference call order.
 
     Int arguments as upstream: the matrix passes buffc (matrix.go:575,597,600,684,691);
     the double array 0, except SentenceEnd(buffc) at EOT (datok.go:1015,1023,1026)."""
@@ -155,9 +173,10 @@ def replay(is_matrix, text: bytes, events, tok_bstart, tw: TokenWriter):
             buf = _decode_runes(text[B:p])
             tw.Token(len(_decode_runes(text[B:start])), buf)
             B = p
-        for bit in (EV_S_EPS, EV_S_EPS2, EV_S_EOF):
-            if e & bit:
-                tw.SentenceEnd(buffc() if is_matrix else 0)
+        if e & EV_S_EPS:
+            tw.SentenceEnd(buffc() if is_matrix else 0)
+        if e & EV_S_EOF:
+            tw.SentenceEnd(buffc() if is_matrix else 0)
         if e & EV_E_EOF:
             tw.TextEnd(buffc() if is_matrix else 0)
 
@@ -236,7 +255,8 @@ class Tokenizer:
         if 0 in exact:                          # walked by the exact pass: its calls are listed in order
             replay_calls(text, exact[0], tw)
         else:
-            events = (arr(v.events, n_ev, np.uint8) & np.uint8(7)) | arr(v.events_open, n_ev, np.uint8)
+            bits = arr(v.ev_bits, 5 * int(v.ev_words), np.uint32).reshape(5, -1)
+            events = event_bytes(bits, 0, 0, len(text), arr(v.doc_tail, 1, np.uint32)[0])
             replay(self.type() == "MATOK", text, events, arr(v.tok_bstart, ntok, np.uint32), tw)
         tw.Flush()                              # `defer w.Flush()`, matrix.go:374
         return not (self.last_status & _FATAL)
@@ -266,15 +286,20 @@ def load_tokenizer_file(path):
 
 
 # ----------------------------------------------------------------------- Batch
-def event_base(doc_off_d, d):
-    """DTK_EVENT_BASE: index of position 0 of document d in the event arrays."""
-    return (int(doc_off_d) + 4 * int(d)) & ~3
+def event_bit(doc_off_d, d):
+    """DTK_EVENT_BIT: bit of position 0 of document d in the event bitmaps."""
+    return int(doc_off_d) + int(d)
 
 
 class BatchResult:
     """Host copy of dtk_result_view (CSR over documents)."""
     __slots__ = ("tok_off", "sent_off", "text_off", "tok_rstart", "tok_rend", "tok_bstart",
-                 "tok_bend", "sent", "text_tok_end", "text_sent_end", "status", "events", "doc_off", "exact")
+                 "tok_bend", "sent", "text_tok_end", "text_sent_end", "status", "ev_bits", "doc_tail", "doc_off", "exact")
+
+    def events(self, d):
+        """Flag byte per cursor position of document d (event_bytes()), for replays."""
+        n = int(self.doc_off[d + 1]) - int(self.doc_off[d])
+        return event_bytes(self.ev_bits, self.doc_off[d], d, n, self.doc_tail[d])
 
     def doc(self, d):
         a, b = int(self.tok_off[d]), int(self.tok_off[d + 1])
@@ -407,9 +432,8 @@ class Batch:
         r.text_tok_end = arr(v.text_tok_end, t["n_texts"], np.uint32)
         r.text_sent_end = arr(v.text_sent_end, t["n_texts"], np.uint32)
         r.status = arr(v.status, nd, np.uint32)
-        n_ev = self.total + 4 * nd + 4
-        # closing events are the low three bits of `events` (the rest is a length field of the device compaction)
-        r.events = (arr(v.events, n_ev, np.uint8) & np.uint8(7)) | arr(v.events_open, n_ev, np.uint8)
+        r.ev_bits = arr(v.ev_bits, 5 * int(v.ev_words), np.uint32).reshape(5, -1)
+        r.doc_tail = arr(v.doc_tail, nd, np.uint32)
         r.doc_off = self._doc_off
         r.exact = _exact_calls(v, arr)   # documents walked by the exact pass: id -> calls in order
         return r

@@ -18,7 +18,7 @@
 //   (*T).Type()               matrix.go:102          Tokenizer::Type()
 //
 // The FSA walk itself runs on the GPU (dtk_batch_run); this header only drains
-// the reader, calls the C-ABI and REPLAYS the returned event bytes into the
+// the reader, calls the C-ABI and REPLAYS the returned events into the
 // caller's four closures in the order the reference would have called them.
 #pragma once
 
@@ -102,27 +102,30 @@ inline int count_runes(const uint8_t *p, size_t n) {
   return k;
 }
 
-// Replays the event bytes of one document (dtk_result_view.events /
-// events_open, n+1 bytes each, plus the token start offsets of that document)
-// into the closures.  Order at one cursor position = bit order of the byte.
-// The int arguments follow the reference: the matrix passes buffc everywhere
-// (matrix.go:575,597,600,684,691), the double array passes 0 except for the
-// SentenceEnd fired by EOT (datok.go:1015,1023,1026,1119,1127).
-inline void replay(bool is_matrix, const uint8_t *text, size_t n, const uint8_t *ev_close,
-                   const uint8_t *ev_open, const uint32_t *tok_bstart, TokenWriter &w) {
+// Replays the events of document d of a host dtk_result_view (the bitmaps of ev_bits, the tail word, the
+// token start offsets) into the closures.  Order at one cursor position: SEOT, TEOT, END, SEPS; the final
+// SentenceEnd / TextEnd come last.  The int arguments follow the reference: the matrix passes buffc everywhere
+// (matrix.go:575,597,600,684,691), the double array passes 0 except for the SentenceEnd fired by EOT
+// (datok.go:1015,1023,1026,1119,1127).
+inline void replay(bool is_matrix, const uint8_t *text, size_t n, const dtk_result_view &v, uint64_t doc_off_d,
+                   uint32_t d, TokenWriter &w) {
+  const uint64_t g0 = DTK_EVENT_BIT(doc_off_d, d);
+  auto bit = [&](int kind, size_t p) {
+    const uint64_t g = g0 + p;
+    return (v.ev_bits[(uint64_t)kind * v.ev_words + (g >> 5)] >> (g & 31)) & 1u;
+  };
+  const uint32_t *tok_bstart = v.tok_bstart + v.tok_off[d];
   size_t B = 0;      // byte position of the window start (last rewind)
   size_t k = 0;      // tokens replayed so far (index into tok_bstart)
   std::vector<rune> buf;
+  auto buffc = [&](size_t p) { return count_runes(text + B, p - B); };
   for (size_t p = 0; p <= n; p++) {
-    const uint8_t e = (uint8_t)((ev_close[p] & DTK_EV_CLOSE_MASK) | ev_open[p]);
-    if (!e) continue;
-    auto buffc = [&]() { return count_runes(text + B, p - B); };
-    if (e & DTK_EV_S_EOT) w.SentenceEnd(buffc());
-    if (e & DTK_EV_E_EOT) {
-      w.TextEnd(is_matrix ? buffc() : 0);
+    if (bit(DTK_EVB_SEOT, p)) w.SentenceEnd(buffc(p));
+    if (bit(DTK_EVB_TEOT, p)) {
+      w.TextEnd(is_matrix ? buffc(p) : 0);
       if (is_matrix) B = p;  // matrix.go:601 rewinds, datok.go:1019-1030 does not
     }
-    if (e & DTK_EV_TOK_END) {
+    if (bit(DTK_EVB_END, p)) {
       const size_t start = tok_bstart[k++];
       buf.clear();
       int offset = 0;
@@ -137,11 +140,12 @@ inline void replay(bool is_matrix, const uint8_t *text, size_t n, const uint8_t 
       w.Token(offset, buf);
       B = p;
     }
-    if (e & DTK_EV_S_EPS) w.SentenceEnd(is_matrix ? buffc() : 0);
-    if (e & DTK_EV_S_EPS2) w.SentenceEnd(is_matrix ? buffc() : 0);
-    if (e & DTK_EV_S_EOF) w.SentenceEnd(is_matrix ? buffc() : 0);
-    if (e & DTK_EV_E_EOF) w.TextEnd(is_matrix ? buffc() : 0);
+    if (bit(DTK_EVB_SEPS, p)) w.SentenceEnd(is_matrix ? buffc(p) : 0);
   }
+  const uint32_t tail = v.doc_tail[d];
+  const size_t pt = tail >> 2;
+  if (tail & DTK_TAIL_S) w.SentenceEnd(is_matrix ? buffc(pt) : 0);
+  if (tail & DTK_TAIL_E) w.TextEnd(is_matrix ? buffc(pt) : 0);
 }
 
 // The same for a document walked by the exact pass (dtk_result_view.calls): the calls are listed in
@@ -171,13 +175,12 @@ inline void replay_calls(const uint8_t *text, size_t n, const dtk_call *calls, s
   }
 }
 
-// one document of a host dtk_result_view (document 0 of a one-stream batch): event bytes, or the
-// call list if the exact pass walked it
+// document 0 of a one-stream batch (host view): its event bitmaps, or the call list if the exact pass walked it
 inline void replay_view(bool is_matrix, const uint8_t *text, size_t n, const dtk_result_view &v, TokenWriter &w) {
   if (v.n_exact && v.exact_doc[0] == 0)
     replay_calls(text, n, v.calls + v.exact_off[0], (size_t)(v.exact_off[1] - v.exact_off[0]), w);
   else
-    replay(is_matrix, text, n, v.events, v.events_open, v.tok_bstart, w);
+    replay(is_matrix, text, n, v, 0, 0, w);
 }
 
 }  // namespace detail

@@ -199,24 +199,24 @@ typedef struct {
   const int32_t *sent;
   const uint32_t *text_tok_end, *text_sent_end;
   const uint32_t *status;
-  /* raw walk output, for replay into TokenWriter closures: one byte per byte
-   * position p = 0..len of every document, at index DTK_EVENT_BASE(doc_off[d], d) + p.  The calls
-   * fired by a window rewind (S_EOT, E_EOT, TOK_END) are in the low three bits of `events`, all
-   * others in `events_open`: (events[i] & DTK_EV_CLOSE_MASK) | events_open[i] is the event byte.
-   * The k-th TOK_END of a document belongs to its k-th token (tok_bstart/tok_bend).  The upper
-   * five bits of `events` carry the token's byte length (31: 31 or more, then DTK_EV_TOK_START
-   * marks its first byte in events_open) -- bookkeeping of the device compaction. */
-  const uint8_t *events;
-  const uint8_t *events_open;
+  /* Raw walk output, for replay into TokenWriter closures: one bitmap per kind of event over the cursor
+   * positions p = 0..len of every document.  Position p of document d is bit DTK_EVENT_BIT(doc_off[d], d) + p;
+   * bitmap k (DTK_EVB_*) is ev_bits[k * ev_words .. (k + 1) * ev_words).  Calls at one cursor position are
+   * fired in the order SEOT, TEOT, END (the token whose first byte is the last START bit below), SEPS.  The
+   * final SentenceEnd / TextEnd (matrix.go:683-691) are in doc_tail[d] = cursor << 2 | DTK_TAIL_S | DTK_TAIL_E.
+   * The k-th END bit of a document belongs to its k-th token (tok_bstart / tok_bend). */
+  const uint32_t *ev_bits;
+  uint64_t ev_words;
+  const uint32_t *doc_tail;
   /* The exact pass.  The event bytes order the calls by cursor position.  Two constructs of the
-   * reference break that order: the double array consuming one EOT rune twice (it keeps its window
+   * reference break that order (or put two calls on one bit): the double array consuming one EOT rune twice (it keeps its window
    * over an EOT, datok.go:1019-1030, so a later backtrack, :916-926, re-reads it: SentenceEnd /
    * TextEnd, then a Token that ends BEFORE them, then both again), and more than two epsilon
    * SentenceEnds at one cursor (matrix.go:573-576 has no limit).  No shipped model does either on
    * any test corpus; a document that does is walked again by a single lane in the reference's own
    * order, which writes its rows of the arrays above (bit-exact like all others) and lists its
    * calls here.  For the n_exact documents exact_doc[i] (ascending) a replay must use
-   * calls[exact_off[i] .. exact_off[i+1]) instead of the event bytes. */
+   * calls[exact_off[i] .. exact_off[i+1]) instead of the event bitmaps. */
   uint32_t n_exact;
   const uint32_t *exact_doc;
   const uint64_t *exact_off; /* n_exact + 1 */
@@ -229,22 +229,19 @@ int dtk_batch_status_host(dtk_batch *b, uint32_t *status, uint32_t n);
  * run / free) and returns host pointers in the same struct. */
 int dtk_batch_result_host(dtk_batch *b, dtk_result_view *out);
 
-/* index of position 0 of document d in dtk_result_view.events / events_open */
-#define DTK_EVENT_BASE(doc_off_d, d) ((((uint64_t)(doc_off_d)) + 4ull * (uint64_t)(d)) & ~3ull)
+/* bit of position 0 of document d in the bitmaps of dtk_result_view.ev_bits */
+#define DTK_EVENT_BIT(doc_off_d, d) (((uint64_t)(doc_off_d)) + (uint64_t)(d))
 
-/* event byte layout of dtk_result_view.events (chronological order = bit order) */
+/* the bitmaps of dtk_result_view.ev_bits, in the order the calls fire at one cursor position (START is no call) */
 enum {
-  DTK_EV_S_EOT = 1,      /* SentenceEnd fired by the EOT rune before this byte (matrix.go:595-598) */
-  DTK_EV_E_EOT = 2,      /* TextEnd fired by that EOT rune (matrix.go:599-600) */
-  DTK_EV_TOK_END = 4,    /* a token ends before this byte */
-  DTK_EV_S_EPS = 8,      /* SentenceEnd from an epsilon arc on an empty token (matrix.go:574-575) */
-  DTK_EV_S_EPS2 = 16,    /* a second one at the same cursor */
-  DTK_EV_S_EOF = 32,     /* final SentenceEnd (matrix.go:683-684) */
-  DTK_EV_E_EOF = 64,     /* final TextEnd (matrix.go:690-691) */
-  DTK_EV_TOK_START = 128,/* events_open only: a token of >= 31 bytes starts at this byte (bookkeeping of the
-                            device compaction; no call of the reference corresponds to it -- replays skip it) */
-  DTK_EV_CLOSE_MASK = 7  /* the event bits of `events` (its upper bits are a length field) */
+  DTK_EVB_END = 0,   /* a token ends before this byte: Token(offset, buf) */
+  DTK_EVB_START = 1, /* ... and this is its first byte */
+  DTK_EVB_SEPS = 2,  /* SentenceEnd from an epsilon arc on an empty token (matrix.go:574-575), after an END here */
+  DTK_EVB_TEOT = 3,  /* TextEnd fired by the EOT rune before this byte (matrix.go:599-600), before an END here */
+  DTK_EVB_SEOT = 4,  /* SentenceEnd fired by that EOT rune (matrix.go:595-598), before its TextEnd */
+  DTK_EVB_KINDS = 5
 };
+enum { DTK_TAIL_S = 1, DTK_TAIL_E = 2 }; /* doc_tail: final SentenceEnd (matrix.go:683-684) / TextEnd (:690-691) */
 
 /* ---- NewTokenWriter(w, bits) (token_writer.go:36-175) for every document of the batch, rendered on
  *      the device: bytes[doc_off[d] .. doc_off[d+1]) is exactly what the reference writes to w for

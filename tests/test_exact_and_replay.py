@@ -16,6 +16,8 @@ import craft
 from conftest import MODELS, ROOT
 from parity import assert_batch_equals_oracle
 
+from datok_amd.host import _decode_runes
+
 NEWLINE_AFTER_EOT = 16
 
 
@@ -30,7 +32,7 @@ def _oracle_calls(om, doc: bytes):
     out = []
     for kind, a, b, c, d in ev:
         if kind == 0:
-            out.append(("T", a, len(doc[b:d].decode("utf-8", "replace")) if d > b else 0, c, d))
+            out.append(("T", a, len(_decode_runes(doc[b:d])) if d > b else 0, c, d))   # Go's rune count
         else:
             out.append(("SE"[kind - 1], a))
     return out
@@ -69,9 +71,8 @@ def _replayed(res, d, doc: bytes, is_matrix):
     if d in res.exact:
         host.replay_calls(doc, res.exact[d], rec)
     else:
-        base = host.event_base(res.doc_off[d], d)
         a, b = int(res.tok_off[d]), int(res.tok_off[d + 1])
-        host.replay(is_matrix, doc, res.events[base:base + len(doc) + 1], res.tok_bstart[a:b], rec)
+        host.replay(is_matrix, doc, res.events(d), res.tok_bstart[a:b], rec)
     return rec.calls
 
 
