@@ -417,8 +417,14 @@ struct EventSink {
   __device__ __forceinline__ void put(uint32_t kind, uint32_t pos) {
     if (DTK_KO & 8) return;
     const uint32_t G = gb + pos, m = 1u << (G & 31u), w = (G >> 5) - w0;
-    if (w < lw) __hip_atomic_fetch_or(&lds[kind * lw + w], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_or_b32
-    else atomicOr(&g[kind * gw + (G >> 5)], m);
+    // (one wave-uniform test keeps the common case free of exec-mask juggling: all lanes inside the LDS range)
+    if (__builtin_amdgcn_ballot_w64(w >= lw) == 0ull) {
+      __hip_atomic_fetch_or(&lds[kind * lw + w], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // ds_or_b32
+    } else if (w < lw) {
+      __hip_atomic_fetch_or(&lds[kind * lw + w], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+      atomicOr(&g[kind * gw + (G >> 5)], m);
+    }
   }
   __device__ __forceinline__ bool in_closing(uint32_t p) const { return p > lo && p <= hi; }
   __device__ __forceinline__ bool in_opening(uint32_t p) const { return p >= lo && p < hi; }
@@ -1640,103 +1646,9 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
   }
 
   const uint32_t n_pos = sr.p1 + 1u;  // cursor positions p0..p1
-  // what the tile before left for the first lane: the START and rune-start words of the 32 positions before
-  // the tile, and the rune index at their first position (a segment starts at a rewind: no token spans it)
-  uint32_t pS_in = 0, pR_in = 0, pRb_in = cR;
-  for (uint32_t T0 = sr.p0; T0 < n_pos; T0 += 32u * WAVE) {
-    // ---- the lane's words: positions q0 .. q0 + 31
-    const uint32_t q0 = T0 + 32u * lane;
-    uint32_t wE = 0, wS = 0, wP = 0, wT = 0, wU = 0, wR = 0;
-    if (q0 < n_pos) {
-      const uint32_t valid = lowmask(n_pos - q0);
-      wE = bits32(bE, gb + q0) & valid; wS = bits32(bS, gb + q0) & valid; wP = bits32(bP, gb + q0) & valid;
-      wT = bits32(bT, gb + q0) & valid; wU = bits32(bU, gb + q0) & valid;
-      if (q0 < len) wR = bits32(A.rs_bits, (uint32_t)off + q0) & lowmask(len - q0);  // rune starts: bit = input byte
-      if (seg_mode) {  // closing kinds in (p0, p1], opening kinds in [p0, p1) or, at the end, [p0, p1]
-        if (q0 == sr.p0) { wE &= ~1u; wT &= ~1u; wU &= ~1u; }
-        if (!sr.last && sr.p1 >= q0 && sr.p1 - q0 < 32u) { wS &= ~(1u << (sr.p1 - q0)); wP &= ~(1u << (sr.p1 - q0)); }
-      }
-    }
-    uint32_t tileR;
-    const uint32_t rB = cR + wave_excl_scan((uint32_t)__popc(wR), tileR);  // rune index at q0
-    // the words of the 32 positions before mine
-    uint32_t pS = __shfl_up(wS, 1), pR = __shfl_up(wR, 1), pRb = __shfl_up(rB, 1);
-    if (lane == 0) { pS = pS_in; pR = pR_in; pRb = pRb_in; }
-    const bool any_eot = __ballot((wT | wU) != 0u) != 0ull;  // wave-uniform: most tiles hold no EOT
-    const bool last_tile = T0 + 32u * WAVE >= n_pos;
 
-    for (uint32_t step = 0; step < 8u; step++) {
-      const uint32_t S0 = T0 + 256u * step;  // first position of the step (wave-uniform)
-      if (S0 >= n_pos) break;
-      // ---- light: my 4 positions P0 .. P0 + 3 live in the word of lane `src`, bits ns .. ns + 3
-      const uint32_t src = 8u * step + (lane >> 3), ns = (lane & 7u) * 4u;
-      const uint32_t P0 = S0 + 4u * lane;
-      const uint32_t xE = __shfl(wE, src), xP = __shfl(wP, src), xS = __shfl(wS, src), xR = __shfl(wR, src);
-      const uint32_t xRb = __shfl(rB, src), yS = __shfl(pS, src), yR = __shfl(pR, src), yRb = __shfl(pRb, src);
-      uint32_t nE = (xE >> ns) & 15u, nP = (xP >> ns) & 15u, nT = 0, nU = 0;
-      if (any_eot) { nT = (__shfl(wT, src) >> ns) & 15u; nU = (__shfl(wU, src) >> ns) & 15u; }
-      const uint32_t evn = nE | nP | nT | nU;  // positions of mine that carry a call
-      uint32_t tot;
-      const uint32_t ex = wave_excl_scan((uint32_t)__popc(evn), tot);
-      uint32_t slot = qhead + qn + ex;
-#pragma unroll
-      for (uint32_t j = 0; j < 4u; j++) {
-        if (evn & (1u << j)) {
-          const uint32_t b = ns + j, at = slot & (CQ_CAP - 1u);
-          const uint32_t R = xRb + (uint32_t)__popc(xR & lowmask(b));
-          qpos[at] = P0 + j;
-          qrn[at] = R;
-          qfl[at] = (uint8_t)(((nU >> j) & 1u) * EV_S_EOT | ((nT >> j) & 1u) * EV_E_EOT | ((nE >> j) & 1u) * EV_TOK_END |
-                              ((nP >> j) & 1u) * EV_S_EPS);
-          if (nE & (1u << j)) {
-            // the token's first byte: the highest START bit below this position
-            uint32_t sp, sr_;
-            const uint32_t m = xS & lowmask(b);
-            if (m) {
-              const uint32_t sb = 31u - (uint32_t)__clz((int)m);
-              sp = P0 + j - (b - sb);
-              sr_ = xRb + (uint32_t)__popc(xR & lowmask(sb));
-            } else if (yS) {
-              const uint32_t sb = 31u - (uint32_t)__clz((int)yS);
-              sp = P0 + j - b - 32u + sb;
-              sr_ = yRb + (uint32_t)__popc(yR & lowmask(sb));
-            } else {  // a token of more than 32 bytes: search backwards (rare)
-              const uint32_t ws = P0 + j - b;  // first position of my word; the 32 before it hold no START
-              uint32_t q = ws >= sr.p0 + 32u ? ws - 32u : sr.p0;
-              uint32_t w = 0;
-              while (!w && q > sr.p0) {
-                const uint32_t n = q - sr.p0 < 32u ? q - sr.p0 : 32u;
-                q -= n;
-                w = bits32(bS, gb + q) & lowmask(n);
-              }
-              sp = w ? q + 31u - (uint32_t)__clz((int)w) : sr.p0;
-              sr_ = R;
-              for (uint32_t z = sp; z < P0 + j; z += 32u)  // rune starts in [sp, position)
-                sr_ -= (uint32_t)__popc(bits32(A.rs_bits, (uint32_t)off + z) & lowmask(P0 + j - z));
-            }
-            qst[at] = sp; qsr[at] = sr_;
-          }
-          slot++;
-        }
-      }
-      qn += tot;
-      __syncthreads();
-      bool drain = last_tile && (step == 7u || S0 + 256u >= n_pos);
-      if (drain && sr.last) {
-        // the final SentenceEnd / TextEnd of the document (matrix.go:683-691): queued behind everything
-        const uint32_t tw = A.doc_tail[d];
-        if (tw & 3u) {
-          if (lane == 0) {
-            const uint32_t at = (qhead + qn) & (CQ_CAP - 1u);
-            qpos[at] = tw >> 2; qrn[at] = cR + tileR;
-            qfl[at] = (uint8_t)(((tw & DTK_TAIL_S) ? EV_S_EOF : 0u) | ((tw & DTK_TAIL_E) ? EV_E_EOF : 0u));
-          }
-          qn += 1u;
-          __syncthreads();
-        }
-      }
-
-      // ---- heavy
+  // ---- heavy: the queued positions, 64 at a time (all of them if `drain`)
+  auto heavy_rounds = [&](bool drain) {
       while (qn >= WAVE || (drain && qn > 0)) {
       const uint32_t take = qn < WAVE ? qn : WAVE;
       uint32_t P = 0, f = 0, R = 0, tb = 0, startP = 0, startR = 0;
@@ -1894,11 +1806,226 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
       cNSev += popc(mS1) + popc(mS2) + popc(mS4);
       cNSent += cTotal;
       }  // heavy rounds
+  };
+
+  // what the tile before left for the first lane: the START and rune-start words of the 32 positions before
+  // the tile, and the rune index at their first position (a segment starts at a rewind: no token spans it)
+  uint32_t pS_in = 0, pR_in = 0, pRb_in = cR;
+  for (uint32_t T0 = sr.p0; T0 < n_pos; T0 += 32u * WAVE) {
+    // ---- the lane's words: positions q0 .. q0 + 31
+    const uint32_t q0 = T0 + 32u * lane;
+    uint32_t wE = 0, wS = 0, wP = 0, wT = 0, wU = 0, wR = 0;
+    if (q0 < n_pos) {
+      const uint32_t valid = lowmask(n_pos - q0);
+      wE = bits32(bE, gb + q0) & valid; wS = bits32(bS, gb + q0) & valid; wP = bits32(bP, gb + q0) & valid;
+      wT = bits32(bT, gb + q0) & valid; wU = bits32(bU, gb + q0) & valid;
+      if (q0 < len) wR = bits32(A.rs_bits, (uint32_t)off + q0) & lowmask(len - q0);  // rune starts: bit = input byte
+      if (seg_mode) {  // closing kinds in (p0, p1], opening kinds in [p0, p1) or, at the end, [p0, p1]
+        if (q0 == sr.p0) { wE &= ~1u; wT &= ~1u; wU &= ~1u; }
+        if (!sr.last && sr.p1 >= q0 && sr.p1 - q0 < 32u) { wS &= ~(1u << (sr.p1 - q0)); wP &= ~(1u << (sr.p1 - q0)); }
+      }
+    }
+    uint32_t tileR;
+    const uint32_t rB = cR + wave_excl_scan((uint32_t)__popc(wR), tileR);  // rune index at q0
+    // the words of the 32 positions before mine
+    uint32_t pS = __shfl_up(wS, 1), pR = __shfl_up(wR, 1), pRb = __shfl_up(rB, 1);
+    if (lane == 0) { pS = pS_in; pR = pR_in; pRb = pRb_in; }
+    const bool any_eot = __ballot((wT | wU) != 0u) != 0ull;  // wave-uniform: most tiles hold no EOT
+
+    if (!any_eot) {
+      // ---- fast: no EOT call in the tile, so the only calls are Token (END) and the epsilon SentenceEnd (SEPS) and
+      //      every lane can work through its own 32 positions: no queue.  What crosses lanes comes from three wave
+      //      scans (tokens, SentenceEnd calls, sentence ints) and a carry chain over two ballots: "is a sentence
+      //      start pending" is a latch -- set by a SentenceEnd, reset by a token end -- whose state before every
+      //      position is the carry vector of  a + b  with generate = SEPS and kill = END & ~SEPS.
+      const uint32_t t0 = cHaveE ? cTokAtLastE : 0u;  // Token calls before the current text
+      uint32_t base = cBase;
+      if (cTE == t0) {  // the text has no token yet: its first one (in this tile or later) fixes the rune base
+        base = cTE == 0u ? ((is_matrix && cHaveE) ? cLastER : 0u)
+                         : (is_matrix ? cLastER + ((nl_rule && cLastEByte == '\n') ? 1u : 0u)
+                                      : cLastEndR + ((nl_rule && cLastEndByte == '\n') ? 1u : 0u));
+      }
+      const uint32_t nTok = (uint32_t)__popc(wE), nP = (uint32_t)__popc(wP);
+      uint32_t tot2;
+      const uint32_t ex2 = wave_excl_scan(nTok | (nP << 16), tot2);
+      const uint32_t tokB = ex2 & 0xFFFFu, pB = ex2 >> 16;  // Token / SentenceEnd calls of the lanes below
+      // the latch
+      const uint32_t la = ~(wE & ~wP), lb = wP;
+      const bool genW = (((uint64_t)la + lb) >> 32) != 0ull, propW = (wE | wP) == 0u;
+      const unsigned long long GG = __ballot(genW), PP = __ballot(propW);
+      const bool pend_in = cTE == 0u || (cNE + cNSev) > cSEatEnd;
+      const unsigned long long cA = GG | PP, carries = (cA + GG + (pend_in ? 1ull : 0ull)) ^ cA ^ GG;
+      const uint32_t cin = (uint32_t)(carries >> lane) & 1u;
+      const uint32_t sfm = wE & ((uint32_t)((uint64_t)la + lb + cin) ^ la ^ lb);  // tokens that start a sentence
+      // a SentenceEnd counts only if its text has a token (token_writer.go:108 panics otherwise)
+      uint32_t vP = wP;
+      if (cTE + tokB <= t0) vP = wE ? (wP & ~lowmask((uint32_t)__ffs((int)wE) - 1u)) : 0u;
+      if (vP != wP) status |= ST_EMPTY_TEXT;
+      uint32_t totS;
+      const uint32_t sentB4 = wave_excl_scan((uint32_t)__popc(sfm) + (uint32_t)__popc(vP), totS);
+      // rune offset of the end of the last token below my word (for SentenceEnds before my first token)
+      const unsigned long long mTokLanes = __ballot(nTok != 0u);
+      int32_t myLastRend = 0;
+      uint32_t myLastR = 0, myLastBit = 0;
+      if (nTok) {
+        myLastBit = 31u - (uint32_t)__clz((int)wE);
+        myLastR = rB + (uint32_t)__popc(wR & lowmask(myLastBit));
+        myLastRend = (int32_t)(myLastR - base);
+      }
+      const unsigned long long below = mTokLanes & lt;
+      const int32_t rendBelow_t = __shfl(myLastRend, below ? highest(below) : 0);
+      const int32_t rendBelowW = below ? rendBelow_t : cLastRend;
+      // tokens
+      uint32_t me = wE, j = 0;
+      while (me) {
+        const uint32_t b = (uint32_t)__ffs((int)me) - 1u;
+        me &= me - 1u;
+        const uint32_t P = q0 + b, R = rB + (uint32_t)__popc(wR & lowmask(b));
+        uint32_t sp, sR;
+        const uint32_t m = wS & lowmask(b);
+        if (m) {
+          const uint32_t sb = 31u - (uint32_t)__clz((int)m);
+          sp = q0 + sb; sR = rB + (uint32_t)__popc(wR & lowmask(sb));
+        } else if (pS) {
+          const uint32_t sb = 31u - (uint32_t)__clz((int)pS);
+          sp = q0 - 32u + sb; sR = pRb + (uint32_t)__popc(pR & lowmask(sb));
+        } else {  // a token of more than 32 bytes: search backwards (rare)
+          uint32_t q = q0 >= sr.p0 + 32u ? q0 - 32u : sr.p0, w = 0;
+          while (!w && q > sr.p0) {
+            const uint32_t n = q - sr.p0 < 32u ? q - sr.p0 : 32u;
+            q -= n;
+            w = bits32(bS, gb + q) & lowmask(n);
+          }
+          sp = w ? q + 31u - (uint32_t)__clz((int)w) : sr.p0;
+          sR = R;
+          for (uint32_t z = sp; z < P; z += 32u) sR -= (uint32_t)__popc(bits32(A.rs_bits, (uint32_t)off + z) & lowmask(P - z));
+        }
+        const uint64_t k = tok_base + cTE + tokB + j;
+        if (k < tok_lim) {
+          A.tok_bstart[k] = sp; A.tok_bend[k] = P;
+          A.tok_rstart[k] = (int32_t)(sR - base); A.tok_rend[k] = (int32_t)(R - base);
+          if (A.tok_sbefore) A.tok_sbefore[k] = cNSev + pB + (uint32_t)__popc(wP & lowmask(b));
+        } else status |= ST_INTERNAL;
+        if (sfm & (1u << b)) {  // token_writer.go:76-79
+          const uint64_t si = sent_base + cNSent + sentB4 + (uint32_t)__popc(sfm & lowmask(b)) + (uint32_t)__popc(vP & lowmask(b));
+          if (si < sent_lim) A.sent[si] = (int32_t)(sR - base); else status |= ST_INTERNAL;
+        }
+        j++;
+      }
+      // SentenceEnds: the end offset of the last token at or below their position (token_writer.go:108)
+      uint32_t mp = vP;
+      while (mp) {
+        const uint32_t b = (uint32_t)__ffs((int)mp) - 1u;
+        mp &= mp - 1u;
+        const uint32_t e = wE & lowmask(b + 1u);
+        int32_t v = rendBelowW;
+        if (e) v = (int32_t)(rB + (uint32_t)__popc(wR & lowmask(31u - (uint32_t)__clz((int)e))) - base);
+        const uint64_t si = sent_base + cNSent + sentB4 + (uint32_t)__popc(sfm & lowmask(b + 1u)) + (uint32_t)__popc(vP & lowmask(b));
+        if (si < sent_lim) A.sent[si] = v; else status |= ST_INTERNAL;
+      }
+      // carries
+      if (mTokLanes) {
+        const int jl = highest(mTokLanes);
+        cLastEndR = __shfl(myLastR, jl);
+        cLastRend = __shfl(myLastRend, jl);
+        cSEatEnd = cNE + cNSev + __shfl(pB + (uint32_t)__popc(wP & lowmask(myLastBit)), jl);
+        cEatEnd = cNE;
+        const uint32_t lastP = __shfl(q0 + myLastBit, jl);
+        cLastEndByte = (nl_rule && lastP < len) ? txt[lastP] : 0u;
+        cBase = base;
+      }
+      cTE += tot2 & 0xFFFFu;
+      cNSev += tot2 >> 16;
+      cNSent += totS;
+    } else {
+      for (uint32_t step = 0; step < 8u; step++) {
+        const uint32_t S0 = T0 + 256u * step;  // first position of the step (wave-uniform)
+        if (S0 >= n_pos) break;
+        // ---- light: my 4 positions P0 .. P0 + 3 live in the word of lane `src`, bits ns .. ns + 3
+        const uint32_t src = 8u * step + (lane >> 3), ns = (lane & 7u) * 4u;
+        const uint32_t P0 = S0 + 4u * lane;
+        const uint32_t xE = __shfl(wE, src), xP = __shfl(wP, src), xS = __shfl(wS, src), xR = __shfl(wR, src);
+        const uint32_t xRb = __shfl(rB, src), yS = __shfl(pS, src), yR = __shfl(pR, src), yRb = __shfl(pRb, src);
+        const uint32_t nE = (xE >> ns) & 15u, nP = (xP >> ns) & 15u;
+        const uint32_t nT = (__shfl(wT, src) >> ns) & 15u, nU = (__shfl(wU, src) >> ns) & 15u;
+        const uint32_t evn = nE | nP | nT | nU;  // positions of mine that carry a call
+        uint32_t tot;
+        const uint32_t ex = wave_excl_scan((uint32_t)__popc(evn), tot);
+        uint32_t slot = qhead + qn + ex;
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; j++) {
+          if (evn & (1u << j)) {
+            const uint32_t b = ns + j, at = slot & (CQ_CAP - 1u);
+            const uint32_t R = xRb + (uint32_t)__popc(xR & lowmask(b));
+            qpos[at] = P0 + j;
+            qrn[at] = R;
+            qfl[at] = (uint8_t)(((nU >> j) & 1u) * EV_S_EOT | ((nT >> j) & 1u) * EV_E_EOT | ((nE >> j) & 1u) * EV_TOK_END |
+                                ((nP >> j) & 1u) * EV_S_EPS);
+            if (nE & (1u << j)) {
+              // the token's first byte: the highest START bit below this position
+              uint32_t sp, sr_;
+              const uint32_t m = xS & lowmask(b);
+              if (m) {
+                const uint32_t sb = 31u - (uint32_t)__clz((int)m);
+                sp = P0 + j - (b - sb);
+                sr_ = xRb + (uint32_t)__popc(xR & lowmask(sb));
+              } else if (yS) {
+                const uint32_t sb = 31u - (uint32_t)__clz((int)yS);
+                sp = P0 + j - b - 32u + sb;
+                sr_ = yRb + (uint32_t)__popc(yR & lowmask(sb));
+              } else {  // a token of more than 32 bytes: search backwards (rare)
+                const uint32_t ws = P0 + j - b;  // first position of my word; the 32 before it hold no START
+                uint32_t q = ws >= sr.p0 + 32u ? ws - 32u : sr.p0;
+                uint32_t w = 0;
+                while (!w && q > sr.p0) {
+                  const uint32_t n = q - sr.p0 < 32u ? q - sr.p0 : 32u;
+                  q -= n;
+                  w = bits32(bS, gb + q) & lowmask(n);
+                }
+                sp = w ? q + 31u - (uint32_t)__clz((int)w) : sr.p0;
+                sr_ = R;
+                for (uint32_t z = sp; z < P0 + j; z += 32u)  // rune starts in [sp, position)
+                  sr_ -= (uint32_t)__popc(bits32(A.rs_bits, (uint32_t)off + z) & lowmask(P0 + j - z));
+              }
+              qst[at] = sp; qsr[at] = sr_;
+            }
+            slot++;
+          }
+        }
+        qn += tot;
+        __syncthreads();
+        heavy_rounds(false);
+        __syncthreads();
+      }
+      heavy_rounds(true);  // nothing stays queued across a tile: the next one may take the fast path
       __syncthreads();
-    }  // steps of the tile
+    }
     // hand the last lane's words to the next tile's first lane
     pS_in = __shfl(wS, WAVE - 1); pR_in = __shfl(wR, WAVE - 1); pRb_in = __shfl(rB, WAVE - 1);
     cR += tileR;
+  }
+  if (sr.last) {
+    // the final SentenceEnd / TextEnd of the document (matrix.go:683-691), behind everything: from the carries
+    const uint32_t tw = A.doc_tail[d];
+    const bool empty = cTE == (cHaveE ? cTokAtLastE : 0u);  // the text has no token (token_writer.go:108,135 panic)
+    if ((tw & 3u) && empty) status |= ST_EMPTY_TEXT;
+    if (tw & DTK_TAIL_S) {
+      if (!empty) {
+        if (sent_base + cNSent < sent_lim) { if (lane == 0) A.sent[sent_base + cNSent] = cLastRend; } else status |= ST_INTERNAL;
+        cNSent++;
+      }
+      cNSev++;
+    }
+    if (tw & DTK_TAIL_E) {
+      if (text_base + cNE < text_lim) {
+        if (lane == 0) {
+          A.text_tok_end[text_base + cNE] = cTE;
+          A.text_sent_end[text_base + cNE] = cNSent;
+          if (A.text_s_end) A.text_s_end[text_base + cNE] = cNSev;
+        }
+      } else status |= ST_INTERNAL;
+      cNE++;
+    }
   }
 
   // the walk's counts sized the rows: they must agree with what was written here
