@@ -729,7 +729,10 @@ struct dtk_batch {
   uint64_t *d_tok_off = nullptr, *d_sent_off = nullptr, *d_text_off = nullptr;
   uint64_t *d_tok_cnt = nullptr, *d_sent_cnt = nullptr, *d_text_cnt = nullptr;  // per-document counts
   uint64_t *d_scan_ws = nullptr;  // tile sums of the multi-block scan (many documents)
-  uint64_t *d_totals = nullptr;  // [0..3] scan totals, [4] walk steps, [5] documents to repair (u32), [6] invalid UTF-8 bytes
+  uint64_t *d_totals = nullptr;  // [0..3] scan totals, [4] walk steps, [6] invalid UTF-8 bytes, [7] irregular flag,
+                                 // [8..9] as u32[4]: documents to repair after the first pass / after each device-side round
+  uint32_t dev_rounds = 0;       // repair rounds enqueued ahead of time in the last run
+  bool expect_repairs = false;   // the last run needed repairs: enqueue rounds ahead of time in the next one
   uint64_t *h_totals = nullptr;  // pinned
   // outputs (grown on demand, never inside a run unless a re-launch is needed)
   uint64_t tok_cap = 0, sent_cap = 0, text_cap = 0;
@@ -821,7 +824,7 @@ extern "C" int dtk_batch_create(uint64_t max_bytes, uint32_t max_docs, dtk_batch
   // per array: total + 4 * n_docs + 4 slots, rounded up to 256 by dtk_batch_run
   // one bit per cursor position and kind: total + n_docs positions, rounded up to 16 bytes per kind, two words of slack
   B_TRY(hipMalloc((void **)&b->d_bits, (EVB_KINDS * ((max_bytes + max_docs) / 32 + 8) + 8) * 4));
-  b->acc_bytes = 64 + 3 * ((uint64_t)max_docs + 1) * 8 + 4 * (uint64_t)max_docs * 4 + 64;
+  b->acc_bytes = 128 + 3 * ((uint64_t)max_docs + 1) * 8 + 4 * (uint64_t)max_docs * 4 + 64;
   B_TRY(hipMalloc((void **)&b->d_acc, b->acc_bytes));
   B_TRY(hipMalloc((void **)&b->d_redo, (uint64_t)max_docs * 4));
   B_TRY(hipMalloc((void **)&b->d_blk_doc, (max_bytes / DTK_SYM_BLOCK_BYTES + 3) * 4));
@@ -1093,6 +1096,19 @@ static int launch_compact2(dtk_batch *b) {
   return DTK_OK;
 }
 
+// One repair round on the batch's stream: spread + reset, clear, then the stages of the first pass restricted to
+// what is repaired; the documents still broken afterwards are counted in *n_bad_out (zero before the round).
+static int repair_round(dtk_batch *b, const dtk_model *m, const DtkWalkArgs *w, const DtkSpecArgs *sp, uint32_t *n_bad_out) {
+  hipStream_t s = b->stream;
+  if (dtk_launch_spec(&m->tab, w, sp, 5, cmp_mask_of(m), b->d_redo, n_bad_out, s) ||
+      dtk_launch_redo_clear(w, sp, s))
+    return hip_fail(hipGetLastError(), "speculative repair");
+  for (int stage = 1; stage <= 4; stage++)
+    if (dtk_launch_spec(&m->tab, w, sp, stage, cmp_mask_of(m), b->d_redo, n_bad_out, s))
+      return hip_fail(hipGetLastError(), "speculative repair");
+  return DTK_OK;
+}
+
 extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
   if (!m || !b) return DTK_E_ARG;
   if (b->n_docs == 0 || !b->d_off) return DTK_E_STATE;
@@ -1119,7 +1135,7 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
     // check words -- cleared together with the two event arrays by one launch
     const size_t nd = b->n_docs;
     uint8_t *q = b->d_acc;
-    b->d_totals = (uint64_t *)q; q += 64;
+    b->d_totals = (uint64_t *)q; q += 128;
     b->d_tok_cnt = (uint64_t *)q; q += (nd + 1) * 8;
     b->d_sent_cnt = (uint64_t *)q; q += (nd + 1) * 8;
     b->d_text_cnt = (uint64_t *)q; q += (nd + 1) * 8;
@@ -1147,20 +1163,33 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
   } else {
     DtkSpecArgs sp = spec_args(b, false);
     sp_first = sp;
-    uint32_t *n_bad = (uint32_t *)(b->d_totals + 5);
+    uint32_t *nb = (uint32_t *)(b->d_totals + 8);  // nb[0]: broken documents after the first pass, nb[r + 1]: after round r
     // DATOK_SPLIT_START=1: start records and chunk walk as two launches (the repair rounds' kernels)
     static const bool split = getenv("DATOK_SPLIT_START") && atoi(getenv("DATOK_SPLIT_START")) != 0;
-    fix_in_scan = b->n_docs <= 8192u;  // k_spec_fix's step rides in the one-block scan kernel
+    // Device-side repair: if the batch's last run had to repair (text with tags, say), two repair rounds are
+    // enqueued right behind the first pass; their kernels return at once when the verification before them found
+    // nothing broken, and the scan / compaction behind them only run once nothing is.  A miss then costs no host
+    // round trip.  (Not done blindly: ten empty launches cost a clean corpus some 15 us per batch.)
+    static const char *e_dr = getenv("DATOK_DEV_ROUNDS");
+    b->dev_rounds = e_dr ? (uint32_t)atoi(e_dr) : (b->expect_repairs ? 2u : 0u);
+    if (b->dev_rounds > 3u) b->dev_rounds = 3u;
+    fix_in_scan = b->n_docs <= 8192u && b->dev_rounds == 0;  // k_spec_fix's step rides in the one-block scan kernel
     for (int stage = 0; stage < 5; stage++) {
       if (((skip & 2) && stage <= 1) || ((skip & 4) && stage == 2) || (stage == 4 && fix_in_scan)) { STAGE(3 + stage); continue; }
       // one launch for start records + walk (timed as "walk"); the link pass, which only reads the
       // records, then runs in front of the verification
       const int what = split ? stage : (stage <= 1 ? -1 : stage == 2 ? 6 : stage);
-      if (!split && stage == 3 && dtk_launch_spec(&m->tab, &w, &sp, 1, cmp_mask_of(m), b->d_redo, n_bad, s))
+      if (!split && stage == 3 && dtk_launch_spec(&m->tab, &w, &sp, 1, cmp_mask_of(m), b->d_redo, nb, s))
         return hip_fail(hipGetLastError(), "speculative walk");
-      if (what >= 0 && dtk_launch_spec(&m->tab, &w, &sp, what, cmp_mask_of(m), b->d_redo, n_bad, s))
+      if (what >= 0 && dtk_launch_spec(&m->tab, &w, &sp, what, cmp_mask_of(m), b->d_redo, nb, s))
         return hip_fail(hipGetLastError(), "speculative walk");
       STAGE(3 + stage);  // ends: start records, link, chunk walk, verify, fix (split) / -, -, start + walk, link + verify, fix
+    }
+    for (uint32_t r = 0; r < b->dev_rounds; r++) {
+      DtkSpecArgs rp = spec_args(b, true);
+      rp.go = nb + r;
+      int rc = repair_round(b, m, &w, &rp, nb + r + 1);
+      if (rc != DTK_OK) return rc;
     }
   }
   DtkCompactArgs c{};
@@ -1172,15 +1201,16 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
   // rows are sized by the walk's own counts (no counting pass)
   if (dtk_launch_scan3(b->d_tok_cnt, b->d_sent_cnt, b->d_text_cnt, b->d_tok_off, b->d_sent_off, b->d_text_off,
                        b->n_docs, b->d_totals, b->d_status, b->d_scan_ws, fix_in_scan ? &sp_first : nullptr, b->d_redo,
-                       (uint32_t *)(b->d_totals + 5), s))
+                       (uint32_t *)(b->d_totals + 8), b->chunk ? (const uint32_t *)(b->d_totals + 8) + b->dev_rounds : nullptr, s))
     return hip_fail(hipGetLastError(), "scan");
   STAGE(8);
+  c.skip_if = b->chunk ? (const uint32_t *)(b->d_totals + 8) + b->dev_rounds : nullptr;
   b->last_args = c;
   int rc = (skip & 8) ? DTK_OK : launch_compact2(b);
   if (rc != DTK_OK) return rc;
   STAGE(9);
 #undef STAGE
-  HIP_TRY(hipMemcpyAsync(b->h_totals, b->d_totals, 8 * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(b->h_totals, b->d_totals, 10 * 8, hipMemcpyDeviceToHost, s));
   b->ran = true;
   b->totals_valid = false;
   b->render_flags = 0xFFFFFFFFu;
@@ -1279,36 +1309,41 @@ static int finish(dtk_batch *b) {
   if (!b->ran) return DTK_E_STATE;
   if (b->totals_valid) return DTK_OK;
   HIP_TRY(hipStreamSynchronize(b->stream));
-  // Speculation check failed somewhere: repair those documents from their first bad lane
-  // on (fix records, clear, re-link, re-walk, re-verify) until every lane chains, then compact again.
-  if (b->chunk != 0 && (uint32_t)b->h_totals[5] != 0) {
-    const dtk_model *m = b->last_model;
-    hipStream_t s = b->stream;
-    DtkWalkArgs w = walk_args(b);
-    uint32_t *n_bad = (uint32_t *)(b->d_totals + 5);
-    while ((uint32_t)b->h_totals[5] != 0) {
-      b->repair_rounds++;
-      DtkSpecArgs sp = spec_args(b, true);
-      HIP_TRY(hipMemsetAsync(n_bad, 0, 8, s));
-      // spread + reset, clear, then the stages of the first pass restricted to what is repaired
-      if (dtk_launch_spec(&m->tab, &w, &sp, 5, cmp_mask_of(m), b->d_redo, n_bad, s) ||
-          dtk_launch_redo_clear(&w, &sp, s))
-        return hip_fail(hipGetLastError(), "speculative repair");
-      for (int stage = 1; stage <= 4; stage++)
-        if (dtk_launch_spec(&m->tab, &w, &sp, stage, cmp_mask_of(m), b->d_redo, n_bad, s))
-          return hip_fail(hipGetLastError(), "speculative repair");
-      HIP_TRY(hipMemcpyAsync(b->h_totals + 5, b->d_totals + 5, 8, hipMemcpyDeviceToHost, s));
+  // Speculation check failed somewhere: those documents are repaired from the last owning lane before their first
+  // bad lane on (fix records, clear, re-link, re-walk, re-verify) until every lane chains.  Rounds enqueued ahead of
+  // time (dtk_batch_run) have run on the device already; what is still broken behind them is repaired from here,
+  // and the scan / compaction -- which did nothing in that case -- run afterwards.
+  if (b->chunk != 0) {
+    const uint32_t *hnb = (const uint32_t *)(b->h_totals + 8);
+    for (uint32_t r = 0; r < b->dev_rounds; r++)
+      if (hnb[r] != 0) b->repair_rounds++;
+    uint32_t left = hnb[b->dev_rounds];
+    if (left != 0) {
+      const dtk_model *m = b->last_model;
+      hipStream_t s = b->stream;
+      DtkWalkArgs w = walk_args(b);
+      uint32_t *n_bad = (uint32_t *)(b->d_totals + 8) + b->dev_rounds;  // (the counter the scan / compaction looked at)
+      while (left != 0) {
+        b->repair_rounds++;
+        DtkSpecArgs sp = spec_args(b, true);
+        HIP_TRY(hipMemsetAsync(n_bad, 0, 4, s));
+        int rc = repair_round(b, m, &w, &sp, n_bad);
+        if (rc != DTK_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(&left, n_bad, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (b->repair_rounds > 1000000u) return DTK_E_STATE;
+      }
+      if (dtk_launch_scan3(b->d_tok_cnt, b->d_sent_cnt, b->d_text_cnt, b->d_tok_off, b->d_sent_off, b->d_text_off,
+                         b->n_docs, b->d_totals, b->d_status, b->d_scan_ws, nullptr, nullptr, nullptr, nullptr, s))
+        return hip_fail(hipGetLastError(), "scan");
+      b->last_args.skip_if = nullptr;
+      int rc = launch_compact2(b);
+      if (rc != DTK_OK) return rc;
+      HIP_TRY(hipMemcpyAsync(b->h_totals, b->d_totals, 5 * 8, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipMemcpyAsync(b->h_totals + 7, b->d_totals + 7, 8, hipMemcpyDeviceToHost, s));
       HIP_TRY(hipStreamSynchronize(s));
-      if (b->repair_rounds > 1000000u) return DTK_E_STATE;
     }
-    if (dtk_launch_scan3(b->d_tok_cnt, b->d_sent_cnt, b->d_text_cnt, b->d_tok_off, b->d_sent_off, b->d_text_off,
-                       b->n_docs, b->d_totals, b->d_status, b->d_scan_ws, nullptr, nullptr, nullptr, s))
-      return hip_fail(hipGetLastError(), "scan");
-    int rc = launch_compact2(b);
-    if (rc != DTK_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(b->h_totals, b->d_totals, 5 * 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(b->h_totals + 7, b->d_totals + 7, 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    b->expect_repairs = b->repair_rounds != 0;
   }
   const uint64_t nt = b->h_totals[0], ns = b->h_totals[1], nx = b->h_totals[2];
   b->n_invalid = b->h_totals[6];

@@ -145,6 +145,9 @@ struct DtkSpecArgs {
   uint32_t first_repair;            // repair rounds: 1 in the round that follows the first pass
   uint32_t warm_extend;             // move the warm-up start back to the previous blank, at most this many bytes (0: off)
   uint32_t lds_words;               // LDS bitmap words per kind for one wave (0: event bits go straight to memory)
+  // A repair round enqueued ahead of time (device-side repair): its kernels return at once unless *go != 0
+  // (the number of documents the previous verification found broken); null: run.
+  const uint32_t *go;
 };
 
 struct DtkWalkArgs {
@@ -193,6 +196,7 @@ struct DtkCompactArgs {
   struct DtkSegIn *seg_in;                // k_seg_scan: the carries a segment starts with
   uint32_t *doc_seq;                      // k_seg_scan: 1 = this long document must be compacted sequentially
   uint32_t *any_irregular;                // set to 1 if a document is flagged ST_IRREGULAR (the host then runs the exact pass)
+  const uint32_t *skip_if;                // documents still to repair: the pass does nothing unless this is 0 (null: run)
 };
 
 #define DTK_SEG_LANES 64u
@@ -282,7 +286,8 @@ uint32_t dtk_render_tiles(uint64_t n);
 int dtk_launch_clear2(void *a, uint64_t a_bytes, void *b, uint64_t b_bytes, void *stream);
 int dtk_launch_scan3(const uint64_t *ca, const uint64_t *cb, const uint64_t *cc, uint64_t *a, uint64_t *b,
                      uint64_t *c, uint32_t n_docs, uint64_t *totals, const uint32_t *status, uint64_t *ws,
-                     const struct DtkSpecArgs *fix_spec, uint32_t *redo_out, uint32_t *n_bad, void *stream);
+                     const struct DtkSpecArgs *fix_spec, uint32_t *redo_out, uint32_t *n_bad, const uint32_t *skip_if,
+                     void *stream);
 #ifdef __cplusplus
 }
 #endif

@@ -1305,6 +1305,7 @@ __device__ __forceinline__ DtkLanePlan plan_of(const DtkSpecArgs &S, uint32_t L,
 // bit-inverted so that a zero fill means "none yet"); the last lane of a document
 // never has one.
 __global__ __launch_bounds__(256) void k_spec_link(DtkSpecArgs S) {
+  if (S.go && *S.go == 0u) return;
   const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
   if (L >= S.n_lanes) return;
   const uint32_t d = S.lane_doc[L];
@@ -1323,6 +1324,7 @@ __global__ __launch_bounds__(WAVE) void k_spec_walk(TRANS tr, DtkWalkArgs A, Dtk
                                                     uint32_t identity) {
   __shared__ uint16_t s_win[WAVE * DTK_WIN_ROW];
   uint16_t *win_row = s_win + threadIdx.x * DTK_WIN_ROW;
+  if (S.go && *S.go == 0u) return;
   uint32_t *lds_bits = S.lds_words ? s_dyn_bits : nullptr;
   const uint32_t L = blockIdx.x * WAVE + threadIdx.x;
   const uint32_t w0 = S.lds_words ? lds_bits_word0(A, S, blockIdx.x * WAVE) : 0u;
@@ -1365,6 +1367,7 @@ __global__ __launch_bounds__(WAVE) void k_spec_walk(TRANS tr, DtkWalkArgs A, Dtk
 // state, flags)?  Lanes that did add their counts / status to the document; the
 // first lane that did not is recorded (bit-inverted, zero = none) in fail_lane[d].
 __global__ __launch_bounds__(256) void k_spec_verify(DtkWalkArgs A, DtkSpecArgs S, uint32_t cmp_mask) {
+  if (S.go && *S.go == 0u) return;
   const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
   bool live = L < S.n_lanes;  // every lane stays for the wave reduction below
   uint32_t d = 0xFFFFFFFFu;
@@ -1440,6 +1443,7 @@ __device__ __forceinline__ void mark_redo(const DtkSpecArgs &S, uint32_t d, uint
 
 __global__ __launch_bounds__(256) void k_spec_fix(DtkWalkArgs A, DtkSpecArgs S, uint32_t *redo_out,
                                                   uint32_t *n_bad) {
+  if (S.go && *S.go == 0u) return;
   const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d >= A.n_docs) return;
   const uint32_t bad = ~S.fail_lane[d];
@@ -1460,6 +1464,7 @@ __global__ __launch_bounds__(256) void k_spec_fix(DtkWalkArgs A, DtkSpecArgs S, 
 //   k_redo_clear  : event bits behind the record the round walks from.
 // then k_spec_link, k_spec_walk (redone lanes only), k_spec_verify (repaired documents only), k_spec_fix.
 __global__ __launch_bounds__(256) void k_redo_spread(DtkSpecArgs S) {
+  if (S.go && *S.go == 0u) return;
   const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
   if (L >= S.n_lanes) return;
   const uint32_t d = S.lane_doc[L];
@@ -1481,6 +1486,7 @@ __global__ __launch_bounds__(256) void k_redo_spread(DtkSpecArgs S) {
 }
 
 __global__ __launch_bounds__(256) void k_redo_reset(DtkWalkArgs A, DtkSpecArgs S) {
+  if (S.go && *S.go == 0u) return;
   const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d >= A.n_docs || S.redo_from[d] == 0xFFFFFFFFu) return;
   A.tok_cnt[d] = 0; A.sent_cnt[d] = 0; A.text_cnt[d] = 0; A.status[d] = 0;
@@ -1492,6 +1498,7 @@ __global__ __launch_bounds__(256) void k_redo_reset(DtkWalkArgs A, DtkSpecArgs S
 // cleared; at that very position only the opening kinds are (the closing kinds there were reported by the lane
 // that stopped at it: a true report that nobody makes again).
 __global__ __launch_bounds__(256) void k_redo_clear(DtkWalkArgs A, DtkSpecArgs S) {
+  if (S.go && *S.go == 0u) return;
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= A.bit_words) return;
   const uint64_t G0 = 32ull * j, G1 = G0 + 32ull;
@@ -1571,6 +1578,7 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
   __shared__ uint8_t qfl[CQ_CAP];
   const bool seg_mode = A.seg_doc != nullptr;
   if (blockIdx.x >= (seg_mode ? A.n_segs : A.n_docs)) return;
+  if (A.skip_if && *A.skip_if != 0u) return;  // documents are still to be repaired: the host runs this pass afterwards
   const uint32_t d = seg_mode ? A.seg_doc[blockIdx.x] : blockIdx.x;
   const uint64_t off = A.doc_off[d];
   const uint32_t len = (uint32_t)(A.doc_off[d + 1] - off);
@@ -2075,6 +2083,7 @@ __device__ __forceinline__ uint32_t runes_between(const uint32_t *__restrict__ b
 __global__ __launch_bounds__(WAVE) void k_seg_sum(DtkCompactArgs A) {
   const uint32_t s = blockIdx.x;
   if (s >= A.n_segs) return;
+  if (A.skip_if && *A.skip_if != 0u) return;
   const uint32_t d = A.seg_doc[s];
   if (A.chunk_off[d + 1] - A.chunk_off[d] <= DTK_SEG_LANES) return;  // a single segment needs no carry
   const uint64_t off = A.doc_off[d];
@@ -2106,6 +2115,7 @@ __global__ __launch_bounds__(WAVE) void k_seg_sum(DtkCompactArgs A) {
 __global__ __launch_bounds__(WAVE) void k_seg_scan(DtkCompactArgs A, const uint32_t *doc_seg0) {
   const uint32_t d = blockIdx.x;
   if (d >= A.n_docs) return;
+  if (A.skip_if && *A.skip_if != 0u) return;
   const uint32_t s0 = doc_seg0[d], s1 = doc_seg0[d + 1];
   if (s1 - s0 <= 1u) return;
   const uint32_t lane = lane_id();
@@ -2156,7 +2166,8 @@ __global__ __launch_bounds__(WAVE) void k_seg_scan(DtkCompactArgs A, const uint3
 __global__ __launch_bounds__(1024) void k_scan3(const uint64_t *ca, const uint64_t *cb, const uint64_t *cc,
                                                 uint64_t *a, uint64_t *b, uint64_t *c, uint32_t n,
                                                 uint64_t *totals, const uint32_t *status, DtkSpecArgs S,
-                                                uint32_t *redo_out, uint32_t *n_bad, int fix) {
+                                                uint32_t *redo_out, uint32_t *n_bad, int fix, const uint32_t *skip_if) {
+  if (skip_if && *skip_if != 0u) return;
   __shared__ uint64_t wsum[3][16];
   __shared__ uint32_t wfl[16];
   const uint32_t T = blockDim.x, tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
@@ -2384,7 +2395,8 @@ __device__ __forceinline__ uint64_t scan_block_excl(uint64_t v, uint64_t *sh, ui
 }
 
 __global__ __launch_bounds__(SCAN_TB) void k_scan3_sums(const uint64_t *ca, const uint64_t *cb, const uint64_t *cc,
-                                                        const uint32_t *status, uint32_t n, uint64_t *ws) {
+                                                        const uint32_t *status, uint32_t n, uint64_t *ws, const uint32_t *skip_if) {
+  if (skip_if && *skip_if != 0u) return;
   __shared__ uint64_t sh[SCAN_TB];
   const uint32_t i0 = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER;
   uint64_t s[4] = {0, 0, 0, 0};
@@ -2397,7 +2409,8 @@ __global__ __launch_bounds__(SCAN_TB) void k_scan3_sums(const uint64_t *ca, cons
 }
 
 __global__ __launch_bounds__(SCAN_TB) void k_scan3_mid(uint64_t *ws, uint32_t nb, uint64_t *a, uint64_t *b, uint64_t *c,
-                                                       uint32_t n, uint64_t *totals) {
+                                                       uint32_t n, uint64_t *totals, const uint32_t *skip_if) {
+  if (skip_if && *skip_if != 0u) return;
   __shared__ uint64_t sh[SCAN_TB];
   const uint32_t tid = threadIdx.x;
   const uint32_t per = (nb + SCAN_TB - 1) / SCAN_TB;
@@ -2419,7 +2432,8 @@ __global__ __launch_bounds__(SCAN_TB) void k_scan3_mid(uint64_t *ws, uint32_t nb
 
 __global__ __launch_bounds__(SCAN_TB) void k_scan3_apply(const uint64_t *ca, const uint64_t *cb, const uint64_t *cc,
                                                          uint64_t *a, uint64_t *b, uint64_t *c, uint32_t n,
-                                                         const uint64_t *ws) {
+                                                         const uint64_t *ws, const uint32_t *skip_if) {
+  if (skip_if && *skip_if != 0u) return;
   __shared__ uint64_t sh[SCAN_TB];
   const uint32_t i0 = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_PER;
   const uint64_t *src[3] = {ca, cb, cc};
@@ -2440,19 +2454,19 @@ __global__ __launch_bounds__(SCAN_TB) void k_scan3_apply(const uint64_t *ca, con
 extern "C" int dtk_launch_scan3(const uint64_t *ca, const uint64_t *cb, const uint64_t *cc, uint64_t *a,
                                 uint64_t *b, uint64_t *c, uint32_t n_docs, uint64_t *totals,
                                 const uint32_t *status, uint64_t *ws, const DtkSpecArgs *fix_spec,
-                                uint32_t *redo_out, uint32_t *n_bad, void *stream) {
+                                uint32_t *redo_out, uint32_t *n_bad, const uint32_t *skip_if, void *stream) {
   hipStream_t s = (hipStream_t)stream;
   if (n_docs <= 8192u || !ws) {
     DtkSpecArgs none{};
     // 1024 threads: the kernel's time is the threads' serial loops over their documents (512: +50 %)
     hipLaunchKernelGGL(k_scan3, dim3(1), dim3(1024), 0, s, ca, cb, cc, a, b, c, n_docs, totals, status,
-                       fix_spec ? *fix_spec : none, redo_out, n_bad, fix_spec ? 1 : 0);
+                       fix_spec ? *fix_spec : none, redo_out, n_bad, fix_spec ? 1 : 0, skip_if);
   } else {
     if (fix_spec) return -1;  // the caller runs k_spec_fix itself for that many documents
     const uint32_t nb = (n_docs + SCAN_TILE - 1) / SCAN_TILE;
-    hipLaunchKernelGGL(k_scan3_sums, dim3(nb), dim3(SCAN_TB), 0, s, ca, cb, cc, status, n_docs, ws);
-    hipLaunchKernelGGL(k_scan3_mid, dim3(1), dim3(SCAN_TB), 0, s, ws, nb, a, b, c, n_docs, totals);
-    hipLaunchKernelGGL(k_scan3_apply, dim3(nb), dim3(SCAN_TB), 0, s, ca, cb, cc, a, b, c, n_docs, ws);
+    hipLaunchKernelGGL(k_scan3_sums, dim3(nb), dim3(SCAN_TB), 0, s, ca, cb, cc, status, n_docs, ws, skip_if);
+    hipLaunchKernelGGL(k_scan3_mid, dim3(1), dim3(SCAN_TB), 0, s, ws, nb, a, b, c, n_docs, totals, skip_if);
+    hipLaunchKernelGGL(k_scan3_apply, dim3(nb), dim3(SCAN_TB), 0, s, ca, cb, cc, a, b, c, n_docs, ws, skip_if);
   }
   return (int)hipGetLastError();
 }
