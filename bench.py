@@ -219,43 +219,45 @@ def main():
         one = {"value": round(total * args.steps / e1 / 1e6, 1), "ms_per_step": round(e1 / args.steps * 1e3, 4),
                "kernel_ms": round(s1["walk"], 4), "stages_ms": {k: round(v, 4) for k, v in s1.items()}}
 
-    # ---- PCIe inclusive: the same batches fed from pinned host memory (set_input: H2D on the batch's stream,
-    #      then the run on the same stream; with several batches the upload of one overlaps the kernels of the others)
+    # ---- PCIe inclusive: the same inputs as one corpus in page-locked host memory, through dtk_pipeline (slices of one
+    #      batch each, three in flight: the upload of a slice overlaps the walk of the others; completion per slice)
     h2d = None
     if rank == 0:
-        pinned = [(torch.from_numpy(t).pin_memory(), o) for t, o in inputs]
-        hb = []
-        for (pt, o) in pinned:
-            bb = datok_amd.Batch(total, n_docs)
-            bb.set_chunking(datok_amd.Batch.AUTO_CHUNK if args.chunk < 0 else args.chunk, args.warm)
-            hb.append(bb)
-        for bb, (pt, o) in zip(hb, pinned):
-            bb.set_input(pt.numpy(), o); bb.run(tok, RUN_FLAGS); bb.totals()
+        reps = max(1, (24 if total <= (64 << 20) else 3) // len(inputs))
+        n_slices = reps * len(inputs)
+        pin = datok_amd.PinnedBuffer(total * n_slices)
+        for i in range(n_slices):
+            pin.array[i * total:(i + 1) * total] = inputs[i % len(inputs)][0]
+        big_off = np.concatenate([inputs[i % len(inputs)][1][(1 if i else 0):] + np.uint64(i * total) for i in range(n_slices)])
+        # plain upload rate of one batch's text, for reference
+        hb = datok_amd.Batch(total, n_docs)
         t0 = time.perf_counter()
-        for i in range(8):
-            bb, (pt, o) = hb[i % len(hb)], pinned[i % len(hb)]
-            bb.set_input(pt.numpy(), o)
-            bb.sync()
-        h2d_ms = (time.perf_counter() - t0) / 8 * 1e3
-        ksteps = max(len(hb) * 4, min(args.steps, 24))
-        t0 = time.perf_counter()
-        ran = [False] * len(hb)
-        for i in range(ksteps):
-            k = i % len(hb)
-            if ran[k]:
-                hb[k].totals()
-            hb[k].set_input(pinned[k][0].numpy(), pinned[k][1])
-            hb[k].run(tok, RUN_FLAGS)
-            ran[k] = True
-        for bb in hb:
-            bb.totals()
-        e2e = time.perf_counter() - t0
+        for i in range(6):
+            hb.set_input(pin.array[(i % n_slices) * total:(i % n_slices + 1) * total], inputs[0][1])
+            hb.sync()
+        h2d_ms = (time.perf_counter() - t0) / 6 * 1e3
+        hb.close()
+        pipe = datok_amd.Pipeline(total, n_docs, depth=3)
+        pipe.set_chunking(datok_amd.Batch.AUTO_CHUNK if args.chunk < 0 else args.chunk, args.warm)
+        done = [0]
+
+        def on_slice(first, n, bb):
+            done[0] += bb.totals()["n_tokens"]
+        pipe.run(tok, pin.array, big_off, RUN_FLAGS, on_slice)      # allocations, lane plans
+        best = 0.0
+        for rep in range(3):
+            done[0] = 0
+            t0 = time.perf_counter()
+            pipe.run(tok, pin.array, big_off, RUN_FLAGS, on_slice)
+            e2e = time.perf_counter() - t0
+            best = max(best, total * n_slices / e2e / 1e6)
+        assert done[0] >= tot["n_tokens"] * reps
         h2d = {"h2d_ms": round(h2d_ms, 4), "h2d_GBps": round(total / h2d_ms / 1e6, 2),
-               "end_to_end_MBps": round(total * ksteps / e2e / 1e6, 1), "steps": ksteps,
-               "what": "pinned host text + offsets -> dtk_batch_set_input -> run -> totals, %d batches in flight" % len(hb)}
-        for bb in hb:
-            bb.close()
-        del pinned
+               "end_to_end_MBps": round(best, 1), "slices": n_slices,
+               "what": "a corpus of %d slices of one batch each in page-locked host memory -> dtk_pipeline_run (depth 3: "
+                       "upload, walk and completion of different slices overlap); results stay in HBM" % n_slices}
+        pipe.close()
+        pin.close()
 
     # ---- offset gather to rank 0 over RCCL (config 5's exchange), outside the clock
     gather_ms, gather_hung, gather_err = None, False, None

@@ -25,6 +25,8 @@ EXPORTS = [
     "dtk_batch_result_device", "dtk_batch_result_host", "dtk_transduce", "dtk_free",
     "dtk_foma_to_matok", "dtk_transduce_replay", "dtk_batch_render_device", "dtk_batch_render_host",
     "dtk_batch_status_host", "dtk_transduce_release", "dtk_transduce_result",
+    "dtk_pipeline_create", "dtk_pipeline_free", "dtk_pipeline_set_chunking", "dtk_pipeline_run",
+    "dtk_pinned_alloc", "dtk_pinned_free",
 ]
 
 
@@ -52,6 +54,9 @@ class ResultView(C.Structure):
                 ("status", C.c_void_p), ("ev_bits", C.c_void_p), ("ev_words", C.c_uint64), ("doc_tail", C.c_void_p),
                 ("n_exact", C.c_uint32), ("exact_doc", C.c_void_p), ("exact_off", C.c_void_p),
                 ("calls", C.c_void_p)]
+
+
+SLICE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p)
 
 
 class RenderView(C.Structure):
@@ -133,6 +138,15 @@ def lib():
     L.dtk_foma_to_matok.restype = C.c_int
     L.dtk_free.argtypes = [vp]
     L.dtk_free.restype = None
+    L.dtk_pipeline_create.argtypes = [u64, u32, u32, C.POINTER(vp)]
+    L.dtk_pipeline_free.argtypes = [vp]
+    L.dtk_pipeline_free.restype = None
+    L.dtk_pipeline_set_chunking.argtypes = [vp, u32, u32]
+    L.dtk_pipeline_run.argtypes = [vp, vp, vp, vp, u32, u32, SLICE_FN, vp]
+    L.dtk_pinned_alloc.restype = vp
+    L.dtk_pinned_alloc.argtypes = [sz]
+    L.dtk_pinned_free.argtypes = [vp]
+    L.dtk_pinned_free.restype = None
     _lib = L
     return L
 

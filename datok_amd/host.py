@@ -439,6 +439,75 @@ class Batch:
         return r
 
 
+class PinnedBuffer:
+    """Page-locked host memory (dtk_pinned_alloc) as a numpy uint8 array: uploads from it are asynchronous."""
+
+    def __init__(self, n):
+        self._p = lib().dtk_pinned_alloc(int(n))
+        if not self._p:
+            raise MemoryError("dtk_pinned_alloc(%d)" % n)
+        self.array = np.frombuffer((C.c_char * int(n)).from_address(self._p), dtype=np.uint8)
+
+    def close(self):
+        p, self._p = getattr(self, "_p", None), None
+        if p:
+            self.array = None
+            lib().dtk_pinned_free(p)
+
+    __del__ = close
+
+
+class Pipeline:
+    """dtk_pipeline: a corpus larger than one batch, cut into slices at document boundaries; the upload of one
+    slice overlaps the walk of the others.  run() calls `on_slice(first_doc, n_docs, batch)` for every finished
+    slice in order (batch: a Batch view of the slice, valid inside the callback)."""
+
+    def __init__(self, slice_bytes, slice_docs, depth=3):
+        self._h = C.c_void_p()
+        check(lib().dtk_pipeline_create(int(slice_bytes), int(slice_docs), int(depth), C.byref(self._h)), "dtk_pipeline_create")
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib().dtk_pipeline_free(h)
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_chunking(self, chunk_bytes=0xFFFFFFFF, warm_bytes=16):
+        check(lib().dtk_pipeline_set_chunking(self._h, int(chunk_bytes), int(warm_bytes)), "dtk_pipeline_set_chunking")
+
+    def run(self, tok, text: np.ndarray, doc_off: np.ndarray, flags=0, on_slice=None):
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        doc_off = np.ascontiguousarray(doc_off, dtype=np.uint64)
+        err = []
+
+        def cb(_user, first, n, handle):
+            if on_slice is None:
+                return 0
+            try:
+                view = Batch.__new__(Batch)
+                view._h = C.c_void_p(handle); view._keep = None; view.n_docs = int(n)
+                view._doc_off = (doc_off[first:first + n + 1] - doc_off[first]).astype(np.uint64)
+                view.total = int(view._doc_off[-1])
+                on_slice(int(first), int(n), view)
+                view._h = None      # the pipeline owns the batch
+                return 0
+            except Exception as e:  # noqa: BLE001  (do not unwind through the C frame)
+                err.append(e)
+                return _lib.E_STATE
+        fn = _lib.SLICE_FN(cb)
+        rc = lib().dtk_pipeline_run(self._h, tok._h, text.ctypes.data, doc_off.ctypes.data, len(doc_off) - 1, flags, fn, None)
+        if err:
+            raise err[0]
+        check(rc, "dtk_pipeline_run")
+
+
 def foma_to_matok(foma_gz: bytes) -> bytes:
     """`datok convert` (cmd/datok.go:50-70, matrix variant): LoadFomaFile + ToMatrix + Save.
 

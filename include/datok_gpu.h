@@ -258,6 +258,24 @@ typedef struct {
 int dtk_batch_render_device(dtk_batch *b, uint32_t bits, dtk_render_view *out);
 int dtk_batch_render_host(dtk_batch *b, uint32_t bits, dtk_render_view *out);
 
+/* ---- streaming: a corpus larger than one batch.  The reference streams any amount of input through a
+ *      bufio.Reader (matrix.go:372); for many documents (one TransduceTokenWriter call each) the counterpart
+ *      here is a pipeline of `depth` batches: the corpus is cut into slices of at most slice_bytes /
+ *      slice_docs at document boundaries, slice i + 1 is uploaded (asynchronously, from page-locked host
+ *      memory, on its batch's own HIP stream) while slice i is walked, and finished slices are handed to
+ *      `fn` in order on the calling thread -- read their results there (dtk_batch_totals / result_* /
+ *      render_*), they are valid until fn returns.  Text in memory from dtk_pinned_alloc is uploaded
+ *      straight from there; other memory is page-locked for the duration of the call. ---- */
+typedef struct dtk_pipeline dtk_pipeline;
+typedef int (*dtk_slice_fn)(void *user, uint32_t first_doc, uint32_t n_docs, dtk_batch *slice); /* DTK_OK to go on */
+int dtk_pipeline_create(uint64_t slice_bytes, uint32_t slice_docs, uint32_t depth, dtk_pipeline **out);
+void dtk_pipeline_free(dtk_pipeline *p);
+int dtk_pipeline_set_chunking(dtk_pipeline *p, uint32_t chunk_bytes, uint32_t warm_bytes);
+int dtk_pipeline_run(dtk_pipeline *p, const dtk_model *m, const uint8_t *text, const uint64_t *doc_off,
+                     uint32_t n_docs, uint32_t flags, dtk_slice_fn fn, void *user);
+void *dtk_pinned_alloc(size_t n); /* page-locked host memory (hipHostMalloc); NULL on failure */
+void dtk_pinned_free(void *p);
+
 /* ---- drop-in for Tokenizer.Transduce / TransduceTokenWriter with a stock
  *      NewTokenWriter(w, bits): what the reference writes to w for ONE stream
  *      (matrix.go:340-348, token_writer.go:36-175).  dtk_transduce walks and renders on the

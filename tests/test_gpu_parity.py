@@ -775,3 +775,43 @@ def test_round1_soak_failure_stays_fixed(gpu, oracle_models):
         b.run(gpu(name), int(z["flags"]))
         res = b.result()
     assert_batch_equals_oracle(oracle_models(name), res, text, off, int(z["flags"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pinned", [True, False])
+def test_pipeline_slices_equal_the_oracle(gpu, oracle_models, pinned):
+    """dtk_pipeline: a ragged corpus cut into slices at document boundaries (by bytes and by document count), three
+    batches in turn, uploads from page-locked memory (dtk_pinned_alloc) or from ordinary memory (page-locked for the
+    call): every slice arrives in order, covers its documents exactly, and every document equals the oracle."""
+    import datok_amd
+    from datok_amd import corpus
+    text, off = corpus.english_zipf_docs(3000, seed=9, max_bytes=16384)
+    tok, om = gpu("tokenizer_en.matok"), oracle_models("tokenizer_en.matok")
+    buf = None
+    if pinned:
+        buf = datok_amd.PinnedBuffer(len(text))
+        buf.array[:] = text
+        src = buf.array
+    else:
+        src = text
+    seen, n_tok = [], [0]
+
+    def on_slice(first, n, b):
+        assert (not seen and first == 0) or first == seen[-1][0] + seen[-1][1]
+        seen.append((first, n))
+        res, tot = b.result(), b.totals()
+        assert tot["n_docs"] == n and tot["n_flagged"] == 0
+        n_tok[0] += tot["n_tokens"]
+        sub_off = (off[first:first + n + 1] - off[first]).astype(np.uint64)
+        sub = text[int(off[first]):int(off[first + n])]
+        assert_batch_equals_oracle(om, res, sub, sub_off, docs=range(0, n, 5))
+    with datok_amd.Pipeline(1 << 20, 400, depth=3) as p:
+        p.run(tok, src, off, 0, on_slice)
+        assert seen[-1][0] + seen[-1][1] == 3000 and len(seen) >= 8
+        assert all(n <= 400 for _, n in seen)
+        counts = om.count_batch(text, off, 4)
+        assert n_tok[0] == int(counts[:, 0].sum())
+        # a second corpus through the same pipeline, no callback
+        p.run(tok, src[:int(off[100])], off[:101], 0, None)
+    if buf is not None:
+        buf.close()
