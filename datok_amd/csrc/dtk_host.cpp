@@ -1150,12 +1150,15 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
     b->d_doc_tail = (uint32_t *)q; q += nd * 4;
     const size_t acc_used = ((size_t)(q - b->d_acc) + 15) & ~(size_t)15;  // the block has 64 bytes of slack
     b->bit_words = (uint32_t)(((b->total + nd) / 32 + 8) & ~(uint64_t)3);  // 16-byte multiples per kind
-    if (dtk_launch_clear2(b->d_acc, acc_used, b->d_bits, (skip & 4) ? 0 : (size_t)EVB_KINDS * b->bit_words * 4, s))
+    // (the event bitmaps are cleared by k_symbolize's blocks, unless it does not run)
+    const bool fold = b->total > 0 && !(skip & 1);
+    if (dtk_launch_clear2(b->d_acc, acc_used, b->d_bits, (fold || (skip & 4)) ? 0 : (size_t)EVB_KINDS * b->bit_words * 4, s))
       return hip_fail(hipGetLastError(), "clear");
   }
   STAGE(1);
   if (!(skip & 1) && dtk_launch_symbolize(b->d_text, b->d_off, b->n_docs, b->total, &m->sig, b->d_sym,
-                           b->d_text == b->d_text_own, b->d_blk_doc, (unsigned long long *)(b->d_totals + 6), b->d_rsbits, s))
+                           b->d_text == b->d_text_own, b->d_blk_doc, (unsigned long long *)(b->d_totals + 6), b->d_rsbits,
+                           b->d_bits, b->bit_words, s))
     return hip_fail(hipGetLastError(), "symbolize");
   STAGE(2);
   DtkWalkArgs w = walk_args(b);

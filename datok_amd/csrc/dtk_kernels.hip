@@ -99,7 +99,8 @@ __global__ __launch_bounds__(WAVE) void k_symbolize(const uint8_t *__restrict__ 
                                                     uint16_t *__restrict__ sym,
                                                     const uint32_t *__restrict__ blk_doc,
                                                     unsigned long long *__restrict__ n_invalid,
-                                                    uint32_t *__restrict__ rs_bits) {
+                                                    uint32_t *__restrict__ rs_bits,
+                                                    uint32_t *__restrict__ ev_bits, uint32_t bit_words) {
   __shared__ uint32_t s_rs[SYM_BLOCK_BYTES / 32];  // bit i: byte i of the block starts a rune
   __shared__ uint16_t lut[128];       // symbol | class | width 1 for the runes < 128 (index = byte)
   __shared__ uint16_t lat[256];       // symbol | class for runes < 256 (heavy path, Latin-1)
@@ -147,6 +148,18 @@ __global__ __launch_bounds__(WAVE) void k_symbolize(const uint8_t *__restrict__ 
   const uint32_t d_lo = blk_doc[blockIdx.x];
   const uint32_t d_hi = min(blk_doc[blockIdx.x + 1], n_docs - 1);
   const uint64_t lo_start = doc_off[d_lo], lo_end = doc_off[d_lo + 1];  // the block's first document
+  if (ev_bits) {
+    // The walk's event bitmaps start from zero: every block clears the words of the cursor positions of its bytes
+    // (bit = byte + document index, dtk_internal.h; neighbours overlap by a word or two), the last block the rest --
+    // a few stores per lane here instead of a 10 MB clear kernel in front.
+    const uint64_t ga = block_start + d_lo, gb = block_start + n_here + d_hi + 1u;
+    const uint32_t wa = (uint32_t)(ga >> 5);
+    uint32_t wb = (uint32_t)((gb + 31u) >> 5);
+    if (wb > bit_words || blockIdx.x == gridDim.x - 1) wb = bit_words;
+    for (uint32_t w = wa + lane; w < wb; w += WAVE)
+#pragma unroll
+      for (uint32_t k = 0; k < EVB_KINDS; k++) ev_bits[(size_t)k * bit_words + w] = 0u;
+  }
   const bool sym16 = ((reinterpret_cast<uintptr_t>(sym) + 2ull * block_start) & 15u) == 0;
 
 #pragma unroll 1
@@ -2234,17 +2247,17 @@ extern "C" int dtk_launch_clear2(void *a, uint64_t a_bytes, void *b, uint64_t b_
 extern "C" int dtk_launch_symbolize(const uint8_t *text, const uint64_t *doc_off, uint32_t n_docs,
                                     uint64_t total, const DtkSigmaDev *sig, uint16_t *sym, int padded,
                                     const uint32_t *blk_doc, unsigned long long *n_invalid, uint32_t *rs_bits,
-                                    void *stream) {
+                                    uint32_t *ev_bits, uint32_t bit_words, void *stream) {
   if (total == 0 || n_docs == 0) return 0;
   const uint32_t blocks = (uint32_t)((total + SYM_BLOCK_BYTES - 1) / SYM_BLOCK_BYTES);
   // ALIGNED4 may read up to 3 bytes past `total`: true for the batch's own (padded) buffer;
   // a caller-owned device buffer only qualifies when its size is a multiple of 4
   if ((((uintptr_t)text) & 3u) == 0 && (padded || (total & 3u) == 0))
     hipLaunchKernelGGL(k_symbolize<true>, dim3(blocks), dim3(WAVE), 0, (hipStream_t)stream, text, doc_off, n_docs,
-                       total, *sig, sym, blk_doc, n_invalid, rs_bits);
+                       total, *sig, sym, blk_doc, n_invalid, rs_bits, ev_bits, bit_words);
   else
     hipLaunchKernelGGL(k_symbolize<false>, dim3(blocks), dim3(WAVE), 0, (hipStream_t)stream, text, doc_off, n_docs,
-                       total, *sig, sym, blk_doc, n_invalid, rs_bits);
+                       total, *sig, sym, blk_doc, n_invalid, rs_bits, ev_bits, bit_words);
   return (int)hipGetLastError();
 }
 
