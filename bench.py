@@ -59,15 +59,9 @@ def parse():
 
 def walk_kernel_name(total_bytes):
     """The dominant kernel as rocprofv3 prints it: start record + chunk walk in one launch (k_spec_both) unless
-    DATOK_SPLIT_START=1; its last template argument says whether event bytes go through LDS lists
-    (batches of 48 MiB and more, dtk_host.cpp spec_args)."""
-    if os.environ.get("DATOK_SPLIT_START", "0") not in ("", "0"):
-        base = "k_spec_walk"
-    else:
-        base = "k_spec_both"
-    e = os.environ.get("DATOK_EV_LISTS")
-    lists = (e not in ("", "0")) if e is not None else total_bytes >= int(os.environ.get("DATOK_EV_LISTS_MIN", 48 << 20))
-    return base + "<%s, true, " + ("true" if lists else "false") + ">"
+    DATOK_SPLIT_START=1."""
+    base = "k_spec_walk" if os.environ.get("DATOK_SPLIT_START", "0") not in ("", "0") else "k_spec_both"
+    return base + "<%s, true>"
 
 
 def timed_steps(batches, tok, steps, barrier):
