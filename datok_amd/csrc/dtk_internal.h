@@ -278,7 +278,8 @@ int dtk_launch_spec(const struct DtkTableDev *tab, const struct DtkWalkArgs *arg
                     const struct DtkSpecArgs *spec, int stage, uint32_t cmp_mask, uint32_t *redo_out,
                     uint32_t *n_bad, void *stream);
 int dtk_launch_redo_clear(const struct DtkWalkArgs *args, const struct DtkSpecArgs *spec, void *stream);
-int dtk_launch_compact(const struct DtkCompactArgs *args, int pass, void *stream);
+int dtk_launch_compact(const struct DtkCompactArgs *args, uint32_t small_max, const uint32_t *big_docs, uint32_t n_big,
+                       void *stream);
 int dtk_launch_exact(const struct DtkTableDev *tab, const struct DtkExactArgs *args, void *stream);
 int dtk_launch_seg_prepare(const struct DtkCompactArgs *args, const uint32_t *doc_seg0, void *stream);
 int dtk_launch_render(const struct DtkRenderArgs *args, int stage, void *stream);

@@ -1586,15 +1586,16 @@ __device__ __forceinline__ uint32_t lowmask(uint32_t n) { return n >= 32u ? 0xFF
 // tracks (token_writer.go:38-42: posC, pos, sentB, sent) is recovered with ballots, popcounts of the lanes
 // below and a handful of shuffles; wave-uniform carries link the rounds.  Order of the calls at one position =
 // bit order of the queued flags.
-__global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
+__global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A, uint32_t small_max, const uint32_t *big_docs) {
   __shared__ uint32_t qpos[CQ_CAP], qrn[CQ_CAP], qst[CQ_CAP], qsr[CQ_CAP];
   __shared__ uint8_t qfl[CQ_CAP];
   const bool seg_mode = A.seg_doc != nullptr;
-  if (blockIdx.x >= (seg_mode ? A.n_segs : A.n_docs)) return;
   if (A.skip_if && *A.skip_if != 0u) return;  // documents are still to be repaired: the host runs this pass afterwards
-  const uint32_t d = seg_mode ? A.seg_doc[blockIdx.x] : blockIdx.x;
+  // one wave per segment, per document, or per document of the list of those that k_compact_small leaves to me
+  const uint32_t d = seg_mode ? A.seg_doc[blockIdx.x] : (big_docs ? big_docs[blockIdx.x] : blockIdx.x);
   const uint64_t off = A.doc_off[d];
   const uint32_t len = (uint32_t)(A.doc_off[d + 1] - off);
+  if (len <= small_max && small_max != 0u) return;  // (segment mode: a small document's one segment)
   const uint32_t gb = (uint32_t)DTK_EV_BIT(off, d);
   const uint32_t *__restrict__ bE = A.bits + (size_t)EVB_END * A.bit_words;
   const uint32_t *__restrict__ bS = A.bits + (size_t)EVB_START * A.bit_words;
@@ -2069,6 +2070,105 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A) {
   }
 }
 
+// ---- small documents: one LANE per document.
+// A wave per document spends most of its instructions on cross-lane bookkeeping; for a batch of many small documents
+// (tens of thousands of tweets or sentences) that is two orders of magnitude more work than the documents hold.
+// Here every lane is NewTokenWriter for its own document (token_writer.go:36-175; same capture semantics as the
+// exact pass): it walks the set bits of its document's bitmap words in position order -- SEOT, TEOT, END, SEPS at
+// one position, then the START bit, which belongs to the next token -- and writes its rows.  k_compact skips these
+// documents (small_max).
+__global__ __launch_bounds__(256) void k_compact_small(DtkCompactArgs A, uint32_t small_max) {
+  if (A.skip_if && *A.skip_if != 0u) return;
+  const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= A.n_docs) return;
+  const uint64_t off = A.doc_off[d];
+  const uint32_t len = (uint32_t)(A.doc_off[d + 1] - off);
+  if (len > small_max) return;
+  if (A.status[d] & ST_IRREGULAR) { atomicOr(A.any_irregular, 1u); return; }
+  if (A.totals[0] > A.tok_cap || A.totals[1] > A.sent_cap || A.totals[2] > A.text_cap) return;
+  const uint64_t tok_base = A.tok_off[d], sent_base = A.sent_off[d], text_base = A.text_off[d];
+  const uint32_t tok_n = (uint32_t)(A.tok_off[d + 1] - tok_base), sent_n = (uint32_t)(A.sent_off[d + 1] - sent_base),
+                 text_n = (uint32_t)(A.text_off[d + 1] - text_base);
+  const uint32_t gb = (uint32_t)DTK_EV_BIT(off, d);
+  const uint32_t *__restrict__ bE = A.bits + (size_t)EVB_END * A.bit_words;
+  const uint32_t *__restrict__ bS = A.bits + (size_t)EVB_START * A.bit_words;
+  const uint32_t *__restrict__ bP = A.bits + (size_t)EVB_SEPS * A.bit_words;
+  const uint32_t *__restrict__ bT = A.bits + (size_t)EVB_TEOT * A.bit_words;
+  const uint32_t *__restrict__ bU = A.bits + (size_t)EVB_SEOT * A.bit_words;
+  const uint8_t *__restrict__ txt = A.text + off;
+  const bool nl_rule = (A.flags & 16u) != 0, is_matrix = A.kind == DTK_KIND_MATRIX;
+  // token_writer.go:38-42, and the window: B = byte position of buffer[0], with its rune index
+  int32_t posC = 0, last_rend = 0;
+  bool init = true, sentB = true;
+  uint32_t n_tok = 0, n_sent = 0, n_text = 0, n_sev = 0, text_tok0 = 0;
+  uint32_t B = 0, RB = 0, cs = 0, Rcs = 0;  // window start; start of the token under way
+  uint32_t st = 0, Rw = 0;                  // rune index at the first position of the word
+  auto sentence_end = [&]() {               // token_writer.go:104-115
+    n_sev++;
+    if (n_tok != text_tok0) {
+      if (n_sent < sent_n) A.sent[sent_base + n_sent] = last_rend; else st |= ST_INTERNAL;
+      n_sent++;
+    }
+    sentB = true;
+  };
+  auto text_end = [&]() {                   // token_writer.go:131-159
+    if (n_text < text_n) {
+      A.text_tok_end[text_base + n_text] = n_tok; A.text_sent_end[text_base + n_text] = n_sent;
+      if (A.text_s_end) A.text_s_end[text_base + n_text] = n_sev;
+    } else st |= ST_INTERNAL;
+    n_text++;
+    sentB = true; posC = 0; text_tok0 = n_tok;
+  };
+  for (uint32_t q0 = 0; q0 <= len; q0 += 32u) {
+    const uint32_t valid = lowmask(len + 1u - q0);
+    const uint32_t wE = bits32(bE, gb + q0) & valid, wS = bits32(bS, gb + q0) & valid, wP = bits32(bP, gb + q0) & valid;
+    const uint32_t wT = bits32(bT, gb + q0) & valid, wU = bits32(bU, gb + q0) & valid;
+    const uint32_t wR = q0 < len ? bits32(A.rs_bits, (uint32_t)off + q0) & lowmask(len - q0) : 0u;
+    uint32_t ev = wE | wS | wP | wT;
+    while (ev) {
+      const uint32_t b = (uint32_t)__ffs((int)ev) - 1u, m = 1u << b;
+      ev &= ev - 1u;
+      const uint32_t p = q0 + b, R = Rw + (uint32_t)__popc(wR & lowmask(b));
+      if (wT & m) {                          // matrix.go:593-605
+        if (wU & m) sentence_end();
+        text_end();
+        if (is_matrix) { B = p; RB = R; }    // matrix.go:601 rewinds, datok.go:1019-1030 does not
+      }
+      if (wE & m) {                          // Token(offset, buf), token_writer.go:58-88
+        if (posC == 0 && nl_rule && p > B && txt[B] == '\n' && !init) posC--;
+        init = false;
+        posC += (int32_t)(Rcs - RB);
+        const int32_t rs = posC;
+        if (sentB) {
+          sentB = false;
+          if (n_sent < sent_n) A.sent[sent_base + n_sent] = rs; else st |= ST_INTERNAL;
+          n_sent++;
+        }
+        posC += (int32_t)(R - Rcs);
+        last_rend = posC;
+        if (n_tok < tok_n) {
+          A.tok_bstart[tok_base + n_tok] = cs; A.tok_bend[tok_base + n_tok] = p;
+          A.tok_rstart[tok_base + n_tok] = rs; A.tok_rend[tok_base + n_tok] = posC;
+          if (A.tok_sbefore) A.tok_sbefore[tok_base + n_tok] = n_sev;
+        } else st |= ST_INTERNAL;
+        n_tok++;
+        B = p; RB = R;
+      }
+      if (wP & m) sentence_end();            // matrix.go:574-575
+      if (wS & m) { cs = p; Rcs = R; }       // the next token starts here
+    }
+    Rw += (uint32_t)__popc(wR);
+  }
+  const uint32_t tw = A.doc_tail[d];         // matrix.go:683-691
+  if (tw & DTK_TAIL_S) sentence_end();
+  if (tw & DTK_TAIL_E) text_end();
+  if (st || n_tok != tok_n || n_sent != sent_n || n_text != text_n) {  // (see k_compact: the exact pass decides)
+    atomicOr(&A.status[d], ST_IRREGULAR);
+    atomicOr(A.any_irregular, 1u);
+  }
+  if (A.doc_ns) A.doc_ns[d] = n_sev;
+}
+
 // ---- long documents: what each segment adds (k_seg_sum), then per document an exclusive scan of
 //      the segments (k_seg_scan) -> the carries k_compact starts a segment with
 
@@ -2370,11 +2470,15 @@ extern "C" int dtk_launch_exact(const DtkTableDev *tab, const DtkExactArgs *args
   });
 }
 
-extern "C" int dtk_launch_compact(const DtkCompactArgs *args, int pass, void *stream) {
+// small_max: documents of at most that many bytes are compacted by one lane each (k_compact_small; 0: none);
+// big_docs / n_big: the other documents (the wave-per-document grid then covers only those; segment mode: all segments)
+extern "C" int dtk_launch_compact(const DtkCompactArgs *args, uint32_t small_max, const uint32_t *big_docs, uint32_t n_big,
+                                  void *stream) {
   if (args->n_docs == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  (void)pass;
-  hipLaunchKernelGGL(k_compact, dim3(args->seg_doc ? args->n_segs : args->n_docs), dim3(WAVE), 0, s, *args);
+  if (small_max) hipLaunchKernelGGL(k_compact_small, dim3((args->n_docs + 255u) / 256u), dim3(256), 0, s, *args, small_max);
+  const uint32_t grid = args->seg_doc ? args->n_segs : (small_max ? n_big : args->n_docs);
+  if (grid) hipLaunchKernelGGL(k_compact, dim3(grid), dim3(WAVE), 0, s, *args, small_max, args->seg_doc ? nullptr : (small_max ? big_docs : nullptr));
   return (int)hipGetLastError();
 }
 
