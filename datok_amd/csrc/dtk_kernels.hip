@@ -90,10 +90,11 @@ __device__ __forceinline__ uint32_t doc_of(const uint64_t *__restrict__ doc_off,
 #define SYM_BLOCK_BYTES DTK_SYM_BLOCK_BYTES
 #define SYM_TILE 512u
 #define SYM_SIG_LDS 64u  // runes >= 256 of the sigma kept in LDS (40 in the shipped models)
-#define SYM_HALF 1024u  // the heavy pass runs once per this many bytes (its queue: 2 B of LDS per byte)
+#define SYM_HALF 1024u  // bytes per wave (its queue of bytes >= 0x80: 2 B of LDS per byte)
+#define SYM_THREADS (WAVE * (SYM_BLOCK_BYTES / SYM_HALF))  // 256: four waves per 4 KiB block
 
 template <bool ALIGNED4>
-__global__ __launch_bounds__(WAVE) void k_symbolize(const uint8_t *__restrict__ text,
+__global__ __launch_bounds__(SYM_THREADS) void k_symbolize(const uint8_t *__restrict__ text,
                                                     const uint64_t *__restrict__ doc_off,
                                                     uint32_t n_docs, uint64_t total, DtkSigmaDev sig,
                                                     uint16_t *__restrict__ sym,
@@ -107,11 +108,12 @@ __global__ __launch_bounds__(WAVE) void k_symbolize(const uint8_t *__restrict__ 
   __shared__ uint32_t s_runes[SYM_SIG_LDS];   // sigma map (runes >= 256), if it fits
   __shared__ uint16_t s_syms[SYM_SIG_LDS];
   __shared__ uint32_t s_txt[SYM_BLOCK_BYTES / 4 + 4];  // the block's bytes, one dword of halo either side
-  __shared__ uint16_t s_q[SYM_HALF];  // positions (offset in the block) of the bytes >= 0x80 of one half
-  const uint32_t lane = threadIdx.x;
+  __shared__ uint16_t s_qs[SYM_BLOCK_BYTES / SYM_HALF][SYM_HALF];  // per wave: positions (offset in the block) of the bytes >= 0x80 of its quarter
+  const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1u), half = tid >> 6;  // one wave per quarter (1 KiB) of the block
+  uint16_t *s_q = s_qs[half];
   const bool sig_lds = sig.n_runes <= SYM_SIG_LDS;
-  for (uint32_t i = lane; i < SYM_BLOCK_BYTES / 32; i += WAVE) s_rs[i] = 0;
-  for (uint32_t i = lane; i < 256u; i += WAVE) {
+  for (uint32_t i = tid; i < SYM_BLOCK_BYTES / 32; i += SYM_THREADS) s_rs[i] = 0;
+  for (uint32_t i = tid; i < 256u; i += SYM_THREADS) {
     // matrix.go:421-426: runes < 256 go through sigmaASCII; rune 4 is EOT
     const uint32_t e = (sig.ascii[i] & DTK_SYM_MASK) | (i == DTK_EOT ? (1u << DTK_SYM_CLS_SHIFT) : 0u);
     lat[i] = (uint16_t)e;
@@ -129,16 +131,16 @@ __global__ __launch_bounds__(WAVE) void k_symbolize(const uint8_t *__restrict__ 
         if (g + k < total) x |= (uint32_t)text[g + k] << (8 * k);
       return x;
     };
-    uint32_t v[SYM_BLOCK_BYTES / 4 / WAVE];
+    uint32_t v[SYM_BLOCK_BYTES / 4 / SYM_THREADS];
 #pragma unroll
-    for (uint32_t r = 0; r < SYM_BLOCK_BYTES / 4 / WAVE; r++) v[r] = load4(block_start + (r * WAVE + lane) * 4u);
+    for (uint32_t r = 0; r < SYM_BLOCK_BYTES / 4 / SYM_THREADS; r++) v[r] = load4(block_start + (r * SYM_THREADS + tid) * 4u);
     uint32_t halo = 0;
-    if (lane == 0 && block_start >= 4) halo = load4(block_start - 4);
-    if (lane == 1) halo = load4(block_start + SYM_BLOCK_BYTES);
+    if (tid == 0 && block_start >= 4) halo = load4(block_start - 4);
+    if (tid == 1) halo = load4(block_start + SYM_BLOCK_BYTES);
 #pragma unroll
-    for (uint32_t r = 0; r < SYM_BLOCK_BYTES / 4 / WAVE; r++) s_txt[1 + r * WAVE + lane] = v[r];
-    if (lane == 0) s_txt[0] = halo;
-    if (lane == 1) s_txt[1 + SYM_BLOCK_BYTES / 4] = halo;
+    for (uint32_t r = 0; r < SYM_BLOCK_BYTES / 4 / SYM_THREADS; r++) s_txt[1 + r * SYM_THREADS + tid] = v[r];
+    if (tid == 0) s_txt[0] = halo;
+    if (tid == 1) s_txt[1 + SYM_BLOCK_BYTES / 4] = halo;
   }
   __syncthreads();
   const uint8_t *__restrict__ sb = reinterpret_cast<const uint8_t *>(s_txt) + 4;  // sb[i] = text[block_start + i]
@@ -156,15 +158,15 @@ __global__ __launch_bounds__(WAVE) void k_symbolize(const uint8_t *__restrict__ 
     const uint32_t wa = (uint32_t)(ga >> 5);
     uint32_t wb = (uint32_t)((gb + 31u) >> 5);
     if (wb > bit_words || blockIdx.x == gridDim.x - 1) wb = bit_words;
-    for (uint32_t w = wa + lane; w < wb; w += WAVE)
+    for (uint32_t w = wa + tid; w < wb; w += SYM_THREADS)
 #pragma unroll
       for (uint32_t k = 0; k < EVB_KINDS; k++) ev_bits[(size_t)k * bit_words + w] = 0u;
   }
   const bool sym16 = ((reinterpret_cast<uintptr_t>(sym) + 2ull * block_start) & 15u) == 0;
 
-#pragma unroll 1
-  for (uint32_t half = 0; half < SYM_BLOCK_BYTES / SYM_HALF; half++) {
-    if (half * SYM_HALF >= n_here) break;
+  // (the four quarters used to be one wave's four rounds: a chain of load -> light -> wait for the stores -> heavy,
+  //  four times over, with four waves per SIMD to hide it; now the rounds are four waves)
+  if (half * SYM_HALF < n_here) {
     // ---- light: every byte < 0x80 is a complete rune: its entry goes straight to memory
     //      (16-byte stores, 8 bytes of input per lane); the positions of the other bytes are queued
     //      (slots from a wave-uniform counter and four ballots: an LDS atomicAdd with per-lane
@@ -211,13 +213,13 @@ __global__ __launch_bounds__(WAVE) void k_symbolize(const uint8_t *__restrict__ 
       if (half * SYM_HALF + it * SYM_TILE >= n_here) break;
       if (full_block) light(std::true_type{}, it); else light(std::false_type{}, it);
     }
-    __syncthreads();
+    // (the queue is the wave's own: no block barrier, the wave's LDS operations complete in order)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     const uint32_t nq = qn;  // wave-uniform
-    if (nq == 0) continue;
     // the heavy lanes overwrite single entries written above: those stores must have landed
     // (staging the block's entries in LDS instead costs more in occupancy than this wait: measured)
-    __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) lgkmcnt(0): stores count in vmcnt on gfx950
-    __syncthreads();
+    if (nq) __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) lgkmcnt(0): stores count in vmcnt on gfx950
 
     // ---- heavy: one queued position per lane
     for (uint32_t q0 = 0; q0 < nq; q0 += WAVE) {
@@ -283,12 +285,11 @@ __global__ __launch_bounds__(WAVE) void k_symbolize(const uint8_t *__restrict__ 
         if (start && wd == 1u) atomicAdd(n_invalid, 1ull);
       }
     }
-    __syncthreads();  // the queue is reused by the next half
   }
   // the block's rune-start bitmap (bit g of the array = input byte g): the compaction counts
   // runes with it instead of reading the symbol stream again
   __syncthreads();
-  for (uint32_t i = lane; i < SYM_BLOCK_BYTES / 32; i += WAVE)
+  for (uint32_t i = tid; i < SYM_BLOCK_BYTES / 32; i += SYM_THREADS)
     if (i * 32u < n_here) rs_bits[(block_start >> 5) + i] = s_rs[i];
 }
 
@@ -2353,10 +2354,10 @@ extern "C" int dtk_launch_symbolize(const uint8_t *text, const uint64_t *doc_off
   // ALIGNED4 may read up to 3 bytes past `total`: true for the batch's own (padded) buffer;
   // a caller-owned device buffer only qualifies when its size is a multiple of 4
   if ((((uintptr_t)text) & 3u) == 0 && (padded || (total & 3u) == 0))
-    hipLaunchKernelGGL(k_symbolize<true>, dim3(blocks), dim3(WAVE), 0, (hipStream_t)stream, text, doc_off, n_docs,
+    hipLaunchKernelGGL(k_symbolize<true>, dim3(blocks), dim3(SYM_THREADS), 0, (hipStream_t)stream, text, doc_off, n_docs,
                        total, *sig, sym, blk_doc, n_invalid, rs_bits, ev_bits, bit_words);
   else
-    hipLaunchKernelGGL(k_symbolize<false>, dim3(blocks), dim3(WAVE), 0, (hipStream_t)stream, text, doc_off, n_docs,
+    hipLaunchKernelGGL(k_symbolize<false>, dim3(blocks), dim3(SYM_THREADS), 0, (hipStream_t)stream, text, doc_off, n_docs,
                        total, *sig, sym, blk_doc, n_invalid, rs_bits, ev_bits, bit_words);
   return (int)hipGetLastError();
 }
