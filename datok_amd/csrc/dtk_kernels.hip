@@ -21,6 +21,7 @@
 #include "dtk_internal.h"
 
 #define WAVE 64
+#define DTK_WARM_TAG 64u  // how far behind a warm-up start an opening angle bracket is looked for
 // knock-out builds for cost measurements (scripts/ko.sh): results are wrong, only timings mean something
 #ifndef DTK_KO
 #define DTK_KO 0
@@ -1175,25 +1176,27 @@ __device__ __forceinline__ DtkLaneState start_record(const TRANS &tr, const DtkW
       // (8 bytes per step: the dwords around them are read whole, a blank is found with byte-wise
       // zero tests on  bytes ^ pattern)
       const uint8_t *tx = S.text + off;
-      const uint32_t lim = sp > S.warm_extend ? sp - S.warm_extend : 0u;
-      uint32_t q = sp;
-      while (q > lim) {
-        // bytes tx[q-8 .. q-1] as one 64-bit word, tx[q-1] on top
-        uint64_t w;
+      // bytes tx[q-8 .. q-1] as one 64-bit word, tx[q-1] on top
+      auto load8 = [&](uint32_t q) -> uint64_t {
         if (off + q >= 16u) {
           const uint64_t a0 = reinterpret_cast<uint64_t>(tx + q) - 8u;  // address of the first of the 8 bytes
           const uint32_t sh = (uint32_t)(a0 & 3u) * 8u;
           const uint32_t *wp = reinterpret_cast<const uint32_t *>(a0 & ~3ull);
           const uint64_t lo64 = (uint64_t)wp[0] | ((uint64_t)wp[1] << 32);
-          w = sh ? (lo64 >> sh) | ((uint64_t)wp[2] << (64u - sh)) : lo64;
-        } else {  // the first bytes of the batch: one by one
-          w = 0;
-          for (uint32_t k = 0; k < 8u; k++)
-            if (q + k >= 8u) w |= (uint64_t)tx[q + k - 8u] << (8u * k);
+          return sh ? (lo64 >> sh) | ((uint64_t)wp[2] << (64u - sh)) : lo64;
         }
-        auto zb = [](uint64_t x) {
-          return ~(((x & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | x) & 0x8080808080808080ull;
-        };
+        uint64_t w = 0;  // the first bytes of the batch: one by one
+        for (uint32_t k = 0; k < 8u; k++)
+          if (q + k >= 8u) w |= (uint64_t)tx[q + k - 8u] << (8u * k);
+        return w;
+      };
+      auto zb = [](uint64_t x) {
+        return ~(((x & 0x7F7F7F7F7F7F7F7Full) + 0x7F7F7F7F7F7F7F7Full) | x) & 0x8080808080808080ull;
+      };
+      const uint32_t lim = sp > S.warm_extend ? sp - S.warm_extend : 0u;
+      uint32_t q = sp;
+      while (q > lim) {
+        const uint64_t w = load8(q);
         uint64_t m = zb(w ^ 0x2020202020202020ull) | zb(w ^ 0x0A0A0A0A0A0A0A0Aull) |
                      zb(w ^ 0x0909090909090909ull) | zb(w ^ 0x0D0D0D0D0D0D0D0Dull);
         if (q < 8u) m &= ~0ull << ((8u - q) * 8u);  // bytes before the document do not count
@@ -1205,6 +1208,24 @@ __device__ __forceinline__ DtkLaneState start_record(const TRANS &tr, const DtkW
       }
       if (q < lim) q = lim;
       sp = q;
+      // Inside a markup tag (<a href="...">, <!-- a comment -->) blanks are no token boundaries: if the nearest
+      // angle bracket behind the start is an opening one, the warm-up starts at it (text with a tag every few hundred
+      // bytes otherwise costs a repair round in every batch).  At most DTK_WARM_TAG bytes back.
+      // (all loads first: one after the other they cost a cache round trip each, 8 us per batch on plain text,
+      //  where no bracket ends the search early)
+      uint64_t wt[DTK_WARM_TAG / 8u];
+#pragma unroll
+      for (uint32_t i = 0; i < DTK_WARM_TAG / 8u; i++) wt[i] = sp > 8u * i ? load8(sp - 8u * i) : 0ull;
+#pragma unroll
+      for (uint32_t i = 0; i < DTK_WARM_TAG / 8u; i++) {
+        const uint32_t qq = sp > 8u * i ? sp - 8u * i : 0u;  // wt[i] = bytes qq-8 .. qq-1
+        uint64_t mo = zb(wt[i] ^ 0x3C3C3C3C3C3C3C3Cull), mc = zb(wt[i] ^ 0x3E3E3E3E3E3E3E3Eull);
+        if (qq < 8u) { const uint64_t in = qq ? ~0ull << ((8u - qq) * 8u) : 0ull; mo &= in; mc &= in; }
+        if (mo | mc) {
+          if (mo > mc) sp = qq - 8u + (7u - ((uint32_t)__clzll((long long)mo) >> 3));  // the nearest one opens a tag
+          break;
+        }
+      }
     }
     EventSink sink;  // (a warm-up reports nothing)
     sink.g = nullptr; sink.lds = (dtk_lds_u32 *)nullptr; sink.tailw = nullptr; sink.lw = 0; sink.lo = sink.hi = 0;
