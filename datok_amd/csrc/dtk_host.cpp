@@ -162,7 +162,11 @@ static size_t parse_sigma(dtk_model *m, const std::vector<uint8_t> &raw, size_t 
 
 static int upload(dtk_model *m, const void *tab, size_t tab_bytes) {
   HIP_TRY(hipGetDevice(&m->device));
-  HIP_TRY(hipMalloc(&m->d_tab, std::max<size_t>(tab_bytes, 16)));
+  // (2048 cells of slack behind the last row: the lean walk asks for its next cell before it knows that the reader is
+  //  at EOF, with whatever stream entry lies behind the document -- any 11-bit symbol index; the cell is not used)
+  const size_t slack = (DTK_SYM_MASK + 1u) * 4u;
+  HIP_TRY(hipMalloc(&m->d_tab, std::max<size_t>(tab_bytes, 16) + slack));
+  HIP_TRY(hipMemset((char *)m->d_tab + tab_bytes, 0, slack));
   HIP_TRY(hipMemcpy(m->d_tab, tab, tab_bytes, hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc((void **)&m->d_ascii, 256 * sizeof(uint16_t)));
   HIP_TRY(hipMemcpy(m->d_ascii, m->ascii, 256 * sizeof(uint16_t), hipMemcpyHostToDevice));
@@ -176,7 +180,7 @@ static int upload(dtk_model *m, const void *tab, size_t tab_bytes) {
     HIP_TRY(hipMemcpy(m->d_runes, m->sigma_runes.data() + first, nr * sizeof(uint32_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(m->d_syms, m->sigma_syms.data() + first, nr * sizeof(uint16_t), hipMemcpyHostToDevice));
   }
-  m->device_bytes = tab_bytes + 512 + nr * 6;
+  m->device_bytes = tab_bytes + slack + 512 + nr * 6;
   m->sig.ascii = m->d_ascii;
   m->sig.runes = m->d_runes;
   m->sig.syms = m->d_syms;

@@ -479,6 +479,28 @@ struct EventSink {
     last_s_p = p;
     put(EVB_SEPS, p);
   }
+  // First pass (k_spec_both), events before the lane's stop position: the window is open-ended and the position lies
+  // inside the wave's LDS bitmaps (their 64 chunks plus a bit per document boundary; DTK_LDS_BIT_WORDS) -- no window
+  // test, no range test.  What a lane reports at or behind its stop position goes through the calls above.
+  __device__ __forceinline__ void put_first(uint32_t kind, uint32_t pos) {
+    if (DTK_KO & 8) return;
+    const uint32_t G = gb + pos, m = 1u << (G & 31u);
+    if (lw) __hip_atomic_fetch_or(&lds[kind * lw + ((G >> 5) - w0)], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else atomicOr(&g[kind * gw + (G >> 5)], m);  // (wave-uniform: no LDS bitmaps configured)
+  }
+  __device__ __forceinline__ void token_first(uint32_t tp, uint32_t p, bool sent_first) {
+    c_tok++;
+    c_sent += sent_first ? 1u : 0u;
+    put_first(EVB_END, p);
+    put_first(EVB_START, tp);
+  }
+  __device__ __forceinline__ void sentence_first(uint32_t p, bool has_tok) {
+    c_sev++;
+    if (has_tok) c_sent++; else st |= ST_EMPTY_TEXT;
+    if (p == last_s_p) st |= ST_IRREGULAR;
+    last_s_p = p;
+    put_first(EVB_SEPS, p);
+  }
   // final SentenceEnd / TextEnd -- matrix.go:683-691
   template <bool IS_MATRIX>
   __device__ __forceinline__ void tail_(uint32_t p, bool sentence_end, bool text_end, bool has_tok) {
@@ -763,7 +785,19 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
 // when any lane of the wave leaves its window all lanes re-base theirs (a wave-uniform branch,
 // once per ~28 iterations).  Read straight from memory in 8-byte groups, the lanes' 64 stream
 // lines and the table lines evict each other from the 32 KiB L1 and every group load goes to L2.
-template <int MODE>
+#ifdef DTK_PROBE
+// (scripts/probe.py) cycles the waves spend waiting for the cell and the entry at the end of an iteration / in the
+// loop / iterations / waves -- chunk walks [0..3], warm-up walks [4..7]
+__device__ unsigned long long g_probe[8];
+extern "C" int dtk_probe_read(unsigned long long *out, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(g_probe), sizeof(g_probe));
+  if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_probe), z, sizeof(z)); }
+  return 0;
+}
+#endif
+
+template <int MODE, bool FIRST = false>
 __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uint16_t *__restrict__ sym_base,
                                            uint64_t off, uint32_t len, DtkLaneState init, uint32_t stop_pos,
                                            EventSink &sink, uint32_t epsilon, uint32_t cap, DtkLaneState &fin,
@@ -822,46 +856,77 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
     }                                                                                                         \
   }
   DTK_EOF_DRAIN()
+  // The loop is rotated: the cell of the NEXT lookup is requested as soon as this one's cell says where the walk goes
+  // (a dozen instructions behind its arrival), and everything else an iteration does -- events, token window, flags,
+  // the epsilon slot -- runs while that request is under way.  In program order the whole iteration used to stand
+  // between a cell's arrival and the next request, and a wave issues in order.  What the rare block decides (hard
+  // fail, EOT, EOF drain) is not known yet when the request leaves: it asks again.
+  //   x  : the cell (t, e)          en : the stream entry behind the rune at p (position p + width(e))
+  uint32_t x = 0, en = 0;
+#define DTK_TAB(t_, e_) (*reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(tab) +                  \
+                                                            ((__umul24((t_), stride) + ((e_) & DTK_SYM_MASK)) << 2)))
+  // the fused table is at most 2^15 states x 2^11 symbols x 4 B: a 32-bit byte offset from the
+  // uniform base (one 24-bit multiply-add) instead of 64-bit address arithmetic
+  if (!done) {
+    x = DTK_TAB(t, e);
+    const uint32_t pn0 = p + ((e >> DTK_SYM_W_SHIFT) & 7u);
+    if (pn0 - wb7 >= DTK_WIN) { wb7 = ((pn0 + o7) & ~7u) - o7; win_fill(row, aligned, wb7 + o7); }
+    en = row[pn0 - wb7];
+  }
+#ifdef DTK_PROBE
+  unsigned long long pr_wait = 0, pr_t0 = clock64(), pr_n = 0;
+#endif
   while (!done) {
     it++;
     const uint32_t w = (e >> DTK_SYM_W_SHIFT) & 7u;     // bytes of the rune at p; 0: an epsilon iteration
-    // the fused table is at most 2^15 states x 2^11 symbols x 4 B: a 32-bit byte offset from the
-    // uniform base (one 24-bit multiply-add) instead of 64-bit address arithmetic
-    const uint32_t x = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(tab) +
-                                                           ((__umul24(t, stride) + (e & DTK_SYM_MASK)) << 2));
-    // while the cell is on its way: the entry of the position the next rune is read from (behind this rune; an
-    // epsilon iteration does this for the position the backtrack returned to)
     const uint32_t pn = p + w;
-    uint32_t e_next;
-    {
-      uint32_t iw = pn - wb7;
-      if (__builtin_amdgcn_ballot_w64(iw >= DTK_WIN) != 0ull) {  // also a backtrack to before the window
-        wb7 = ((pn + o7) & ~7u) - o7;
-        win_fill(row, aligned, wb7 + o7);
-        iw = pn - wb7;
-      }
-      e_next = row[iw];
-    }
-    hi = max(hi, pn);                                   // matrix.go:388-408
     // matrix.go:442-454.  (An epsilon iteration -- state and position of the slot it was popped from -- would put
     // the same slot back; it is dropped again below because every epsilon step drops it.)
     const bool he = t <= n_eps;
     eps_t = he ? t : eps_t; eps_p = he ? p : eps_p;
     const bool r = w == 0u;
     const uint32_t tgt = x & 0x7FFFu, via = (x >> 16) & 0x7FFFu;
-    const bool nontoken = (x & 0x8000u) != 0;
     const bool comp = (int32_t)x < 0;                   // a fused cell: the epsilon arc of t, then the rune from there
     const bool plain = (int32_t)x > 0;
     const bool fail = x == 0u;
-    const bool epsE = comp || (plain && r);             // an epsilon arc is taken at p
     const bool advance = comp || (plain && !r);         // the rune is consumed, matrix.go:579-591
+    const bool backtrack = fail && !r && eps_t != 0;    // matrix.go:487-497
+    // ---- where the walk goes, and the request for its cell
+    const uint32_t t_n = backtrack ? eps_t : (fail ? t : tgt);
+    const uint32_t p_n = backtrack ? eps_p : (advance ? pn : p);
+    // right after a backtrack the bare epsilon symbol: width 0, that iteration consumes nothing (matrix.go:487-497)
+    const uint32_t e_n = backtrack ? epsilon : en;
+    const uint32_t x_n = DTK_TAB(t_n, e_n);
+    uint32_t en_n;
+    {
+      const uint32_t pn_n = p_n + ((e_n >> DTK_SYM_W_SHIFT) & 7u);
+      uint32_t iw = pn_n - wb7;
+      if (__builtin_amdgcn_ballot_w64(iw >= DTK_WIN) != 0ull) {  // also a backtrack to before the window
+        wb7 = ((pn_n + o7) & ~7u) - o7;
+        win_fill(row, aligned, wb7 + o7);
+        iw = pn_n - wb7;
+      }
+      en_n = row[iw];
+    }
+    // ---- this iteration's bookkeeping, under the request
+    hi = max(hi, pn);                                   // matrix.go:388-408
+    const bool nontoken = (x & 0x8000u) != 0;
+    const bool epsE = comp || (plain && r);             // an epsilon arc is taken at p
     const bool flush = epsE && p > tp;                  // matrix.go:565-572
     const bool sentE = epsE && p <= tp;                 // matrix.go:573-576
-    const bool backtrack = fail && !r && eps_t != 0;    // matrix.go:487-497
     const bool hardfail = fail && !backtrack;
+    // (first pass: an epsilon step at or behind the stop position is the rare block's -- the lane's last token, or a
+    //  SentenceEnd on its way there; the positions before it need no test, see EventSink::put_first)
+    const bool beyond = MODE != MODE_DOC && p >= stop_pos;
+    const uint32_t tp_old = tp, F_old = F;
     if (MODE != MODE_START && !(DTK_KO & 1)) {
-      if (flush) sink.template token<true>(bs, tp, p, ((F ^ 4u) & 7u) != 0);
-      if (sentE) sink.template sentence<true>(bs, p, (F & 8u) != 0);
+      if (FIRST) {
+        if (flush && !beyond) sink.token_first(tp, p, ((F ^ 4u) & 7u) != 0);
+        if (sentE && !beyond) sink.sentence_first(p, (F & 8u) != 0);
+      } else {
+        if (flush) sink.template token<true>(bs, tp, p, ((F ^ 4u) & 7u) != 0);
+        if (sentE) sink.template sentence<true>(bs, p, (F & 8u) != 0);
+      }
     }
     const uint32_t win = (DTK_KO & 2) ? 0u : hi - bs;   // bytes the window holds (before this iteration's rewind)
     const uint32_t bs_old = bs, p_old = p;
@@ -870,20 +935,25 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
     const bool skip = nontoken && (comp || (advance && p_old == tp));  // matrix.go:584-588
     tp = (comp || flush) ? p_old : tp;
     tp = skip ? pn : tp;
-    p = backtrack ? eps_p : (advance ? pn : p_old);
-    t = backtrack ? eps_t : (fail ? t : tgt);
     // the epsilon slot: dropped by a backtrack and by every epsilon step; a fused cell remembers the state it
     // read its rune in (the epsilon target, at p_old) if that state has an epsilon arc
     const bool he2 = comp && via <= n_eps;
     eps_t = he2 ? via : ((backtrack || epsE) ? 0u : eps_t);
     eps_p = he2 ? p_old : eps_p;
-    const uint32_t e_cur = e;
-    e = backtrack ? epsilon : e_next;
+    const uint32_t e_cur = e, e_next = en;
+    p = p_n; t = t_n; e = e_n; x = x_n; en = en_n;
     // everything that happens less than once per token: hard fail, EOT, the first rewind at or behind the end of
-    // the chunk (a fused cell's too: the lane then ends BEFORE the cell's rune), the window limit, the lookup cap
+    // the chunk (a fused cell's too: the lane then ends BEFORE the cell's rune), the window limit, the lookup cap,
+    // the reader at EOF
     const bool eot_now = advance && ((e_cur >> DTK_SYM_CLS_SHIFT) & 3u) == 1u;  // matrix.go:593-605
-    const bool at_stop = MODE != MODE_DOC && flush && p_old >= stop_pos;
-    if (hardfail || eot_now || at_stop || (flush && win > DTK_WINDOW) || win > DTK_WINDOW_BYTES || it > cap) {
+    const bool at_stop = flush && beyond;
+    // (one chain of bit operations: `||` makes the compiler branch between the tests)
+    if (hardfail | eot_now | (beyond & (FIRST ? epsE : flush)) | (flush & (win > DTK_WINDOW)) | (win > DTK_WINDOW_BYTES) |
+        (it > cap) | ((p >= len) & !backtrack)) {
+      if (FIRST && MODE != MODE_START && beyond && !(DTK_KO & 1)) {  // what the common path left to this block
+        if (flush) sink.template token<true>(bs_old, tp_old, p_old, ((F_old ^ 4u) & 7u) != 0);
+        if (sentE) sink.template sentence<true>(bs_old, p_old, (F_old & 8u) != 0);
+      }
       if (flush && win > DTK_WINDOW && count_runes(s, bs_old, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
       if (at_stop) {
         // the state right after the rewind at p_old: the target of the epsilon arc
@@ -928,9 +998,41 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
         // position: every document keeps its TextEnd.)
         if (hi - bs > DTK_WINDOW_BYTES && !done) { st |= ST_WINDOW_OVERFLOW; done = true; }
       }
+      if (!done && !backtrack) { DTK_EOF_DRAIN() }
+      if (!done) {  // ask again: state, position or entry may have changed
+        x = DTK_TAB(t, e);
+        const uint32_t pn2 = p + ((e >> DTK_SYM_W_SHIFT) & 7u);
+        if (pn2 - wb7 >= DTK_WIN) { wb7 = ((pn2 + o7) & ~7u) - o7; win_fill(row, aligned, wb7 + o7); }
+        en = row[pn2 - wb7];
+      }
     }
-    if (!done && !backtrack) { DTK_EOF_DRAIN() }
+#ifdef DTK_PROBE
+    {  // the end of the iteration: what is left of the wait for the next cell and entry
+      const unsigned long long a_ = clock64();
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      pr_wait += clock64() - a_;
+      pr_n++;
+    }
+#endif
   }
+#undef DTK_TAB
+#ifdef DTK_PROBE
+  {
+    // (the wave's clock: every lane reads the same counter; the wave leaves the loop with its last lane)
+    const unsigned long long tot_ = clock64() - pr_t0;
+    unsigned long long wmax = pr_wait, nmax = pr_n;
+    for (int o = 32; o; o >>= 1) {
+      const unsigned long long a_ = __shfl_xor(wmax, o), b_ = __shfl_xor(nmax, o);
+      wmax = a_ > wmax ? a_ : wmax; nmax = b_ > nmax ? b_ : nmax;
+    }
+    if (MODE == MODE_CHUNK && lane_id() == 0) {
+      atomicAdd(&g_probe[0], wmax); atomicAdd(&g_probe[1], tot_); atomicAdd(&g_probe[2], nmax); atomicAdd(&g_probe[3], 1ull);
+    }
+    if (MODE == MODE_START && lane_id() == 0) {
+      atomicAdd(&g_probe[4], wmax); atomicAdd(&g_probe[5], tot_); atomicAdd(&g_probe[6], nmax); atomicAdd(&g_probe[7], 1ull);
+    }
+  }
+#endif
 #undef DTK_EOF_DRAIN
 
   if (fin.p == 0xFFFFFFFFu && !(st & (ST_STEP_LIMIT | ST_BAD_MODEL))) {
@@ -948,14 +1050,14 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
 }
 
 // the lean walk: fused cells and no arc on `unknown` (MatrixLeanTrans, picked by the launcher)
-template <typename TRANS, bool IS_MATRIX, int MODE>
+template <typename TRANS, bool IS_MATRIX, int MODE, bool FIRST = false>
 __device__ __forceinline__ void walk_any(const TRANS &tr, const uint16_t *__restrict__ sym_base, uint64_t off,
                                          uint32_t len, DtkLaneState init, uint32_t stop_pos, EventSink &sink,
                                          uint32_t epsilon, uint32_t unknown, uint32_t identity, uint32_t cap,
                                          DtkLaneState &fin, uint32_t &st_out, uint32_t &steps_out,
                                          uint16_t *win_row) {
   if constexpr (TRANS::LEAN)
-    walk_fused<MODE>(tr, sym_base, off, len, init, stop_pos, sink, epsilon, cap, fin, st_out, steps_out, win_row);
+    walk_fused<MODE, FIRST>(tr, sym_base, off, len, init, stop_pos, sink, epsilon, cap, fin, st_out, steps_out, win_row);
   else
     walk_lane<TRANS, IS_MATRIX, MODE>(tr, sym_base, off, len, init, stop_pos, sink, epsilon, unknown, identity, cap,
                                       fin, st_out, steps_out, win_row);
@@ -1139,6 +1241,17 @@ __global__ __launch_bounds__(WAVE) void k_walk_doc(TRANS tr, DtkWalkArgs A, uint
 //                  fails is repaired from the first bad lane on (host loop,
 //                  normally never entered) -- the result is exact either way.
 
+#ifdef DTK_PROBE
+__shared__ unsigned long long s_probe_mark;
+__device__ unsigned long long g_phase[8];  // cycles per wave: prologue+search, warm-up walk, chunk walk, epilogue; waves
+extern "C" int dtk_phase_read(unsigned long long *out, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(g_phase));
+  if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)); }
+  return 0;
+}
+#endif
+
 // the start record of lane k >= 0 of document d (k_spec_start, k_spec_both)
 template <typename TRANS, bool IS_MATRIX>
 __device__ __forceinline__ DtkLaneState start_record(const TRANS &tr, const DtkWalkArgs &A, const DtkSpecArgs &S,
@@ -1227,6 +1340,9 @@ __device__ __forceinline__ DtkLaneState start_record(const TRANS &tr, const DtkW
         }
       }
     }
+#ifdef DTK_PROBE
+    s_probe_mark = clock64();  // (the wave is in lockstep: every lane that comes here writes the same time)
+#endif
     EventSink sink;  // (a warm-up reports nothing)
     sink.g = nullptr; sink.lds = (dtk_lds_u32 *)nullptr; sink.tailw = nullptr; sink.lw = 0; sink.lo = sink.hi = 0;
     uint32_t st;
@@ -1275,6 +1391,11 @@ __global__ __launch_bounds__(WAVE) void k_spec_both(TRANS tr, DtkWalkArgs A, Dtk
   __shared__ uint16_t s_win[WAVE * DTK_WIN_ROW];
   uint16_t *win_row = s_win + threadIdx.x * DTK_WIN_ROW;
   uint32_t *lds_bits = S.lds_words ? s_dyn_bits : nullptr;
+#ifdef DTK_PROBE
+  const unsigned long long pt0 = clock64();
+  unsigned long long pt1 = pt0, pt2 = pt0;
+  s_probe_mark = pt0;
+#endif
   const uint32_t L = blockIdx.x * WAVE + threadIdx.x;
   const uint32_t w0 = S.lds_words ? lds_bits_word0(A, S, blockIdx.x * WAVE) : 0u;
   if (lds_bits) lds_bits_clear(lds_bits, S.lds_words);
@@ -1286,6 +1407,9 @@ __global__ __launch_bounds__(WAVE) void k_spec_both(TRANS tr, DtkWalkArgs A, Dtk
     const uint32_t len = (uint32_t)(A.doc_off[d + 1] - off);
     const DtkLaneState rec =
         start_record<TRANS, IS_MATRIX>(tr, A, S, k, off, len, epsilon, unknown, identity, win_row, steps);
+#ifdef DTK_PROBE
+    pt1 = clock64();
+#endif
     S.lane_start[L] = rec;
     DtkLaneState fin{0xFFFFFFFFu, 0u, 0u, LANE_F_IDLE};
     DtkLaneCount cnt{0u, 0u, 0u, 0u, 0u, 0xFFFFFFFFu, 0u, 0u};
@@ -1299,18 +1423,31 @@ __global__ __launch_bounds__(WAVE) void k_spec_both(TRANS tr, DtkWalkArgs A, Dtk
       EventSink sink;
       sink.init(A, off, d, rec.p, 0xFFFFFFFFu, lds_bits, S.lds_words, w0);
       uint32_t st = 0, steps2 = 0;
-      walk_any<TRANS, IS_MATRIX, MODE_CHUNK>(tr, A.sym, off, len, rec, stop, sink, epsilon, unknown,
-                                              identity, step_cap(A.step_factor, len), fin, st, steps2, win_row);
+      walk_any<TRANS, IS_MATRIX, MODE_CHUNK, true>(tr, A.sym, off, len, rec, stop, sink, epsilon, unknown,
+                                                    identity, step_cap(A.step_factor, len), fin, st, steps2, win_row);
       steps += steps2;
       if (sink.dropped) fin.flags |= LANE_F_DROPPED;
       cnt.tok = sink.c_tok; cnt.sent = sink.c_sent; cnt.text = sink.c_text; cnt.status = st | sink.st;
       cnt.sev = sink.c_sev; cnt.e_pos = sink.e_pos; cnt.e_tok = sink.e_tok;
     }
+#ifdef DTK_PROBE
+    pt2 = clock64();
+#endif
     S.lane_end[L] = fin;
     S.lane_cnt[L] = cnt;
   }
   if (lds_bits) lds_bits_flush(lds_bits, S.lds_words, A.bits, A.bit_words, w0);
   add_steps(A.steps, steps);
+#ifdef DTK_PROBE
+  {
+    __syncthreads();
+    const unsigned long long pt3 = clock64(), mark = s_probe_mark;
+    if (threadIdx.x == 0) {
+      atomicAdd(&g_phase[0], mark - pt0); atomicAdd(&g_phase[1], pt1 - mark); atomicAdd(&g_phase[2], pt2 - pt1);
+      atomicAdd(&g_phase[3], pt3 - pt2); atomicAdd(&g_phase[4], 1ull);
+    }
+  }
+#endif
 }
 
 // Every lane derives its window from the start records and first_bad[d] (k_spec_link), in the
