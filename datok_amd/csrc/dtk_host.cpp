@@ -740,6 +740,8 @@ struct dtk_batch {
                                  // [8..9] as u32[4]: documents to repair after the first pass / after each device-side round
   uint32_t dev_rounds = 0;       // repair rounds enqueued ahead of time in the last run
   bool expect_repairs = false;   // the last run needed repairs: enqueue rounds ahead of time in the next one
+  bool expect_eot = false;       // the last run had documents with EOT calls: launch their compaction kernel with the run
+  bool ran_full = false;         // that kernel has run since the last dtk_batch_run
   uint64_t *h_totals = nullptr;  // pinned
   uint64_t *h_off_pin = nullptr; // pinned staging of the document offsets (a copy from pageable memory would block until
                                  // the text copy in front of it has finished: 0.7 ms per 16 MiB batch)
@@ -1102,7 +1104,8 @@ static uint32_t cmp_mask_of(const dtk_model *m) {
   return LANE_F_SENT | LANE_F_TEXT | (m->unknown_used ? LANE_F_OK : 0u);
 }
 
-static int launch_compact2(dtk_batch *b) {
+// which: 1 the documents without an EOT call, 2 those with one, 3 both (dtk_launch_compact)
+static int launch_compact2(dtk_batch *b, int which) {
   DtkCompactArgs a = b->last_args;
   a.tok_rstart = b->d_rstart; a.tok_rend = b->d_rend;
   a.tok_bstart = b->d_bstart; a.tok_bend = b->d_bend;
@@ -1120,11 +1123,13 @@ static int launch_compact2(dtk_batch *b) {
   a.seg_sum = b->d_seg_sum; a.seg_in = b->d_seg_in;
   a.doc_seq = b->d_seg_tab + 3 * (size_t)b->seg_cap + b->max_docs + 1;
   a.any_irregular = (uint32_t *)(b->d_totals + 7);
+  a.any_eot = a.any_irregular + 1;
   b->last_args = a;
-  if (seg && dtk_launch_seg_prepare(&a, b->d_seg_tab + 3 * (size_t)b->seg_cap, b->stream))
+  if (seg && (which & 1) && dtk_launch_seg_prepare(&a, b->d_seg_tab + 3 * (size_t)b->seg_cap, b->stream))
     return hip_fail(hipGetLastError(), "segment carries");
-  if (dtk_launch_compact(&a, b->small_max, b->d_big_docs, b->n_big, b->stream))
+  if (dtk_launch_compact(&a, b->small_max, b->d_big_docs, b->n_big, which, b->stream))
     return hip_fail(hipGetLastError(), "compact pass 2");
+  if (which & 2) b->ran_full = true;
   return DTK_OK;
 }
 
@@ -1241,7 +1246,11 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
   STAGE(8);
   c.skip_if = b->chunk ? (const uint32_t *)(b->d_totals + 8) + b->dev_rounds : nullptr;
   b->last_args = c;
-  int rc = (skip & 8) ? DTK_OK : launch_compact2(b);
+  // (the kernel for documents with EOT calls only if this batch object's last run had such documents; finish()
+  //  launches it when the other kernel reports one after all)
+  b->ran_full = false;
+  static const bool eager_full = getenv("DATOK_COMPACT_FULL") != nullptr;  // (tests: both kernels with every run)
+  int rc = (skip & 8) ? DTK_OK : launch_compact2(b, (b->expect_eot || eager_full) ? 3 : 1);
   if (rc != DTK_OK) return rc;
   STAGE(9);
 #undef STAGE
@@ -1372,7 +1381,7 @@ static int finish(dtk_batch *b) {
                          b->n_docs, b->d_totals, b->d_status, b->d_scan_ws, nullptr, nullptr, nullptr, nullptr, s))
         return hip_fail(hipGetLastError(), "scan");
       b->last_args.skip_if = nullptr;
-      int rc = launch_compact2(b);
+      int rc = launch_compact2(b, 3);
       if (rc != DTK_OK) return rc;
       HIP_TRY(hipMemcpyAsync(b->h_totals, b->d_totals, 5 * 8, hipMemcpyDeviceToHost, s));
       HIP_TRY(hipMemcpyAsync(b->h_totals + 7, b->d_totals + 7, 8, hipMemcpyDeviceToHost, s));
@@ -1385,9 +1394,21 @@ static int finish(dtk_batch *b) {
   if (nt > b->tok_cap || ns > b->sent_cap || nx > b->text_cap) {
     int rc = alloc_outputs(b, nt + nt / 8 + 16, ns + ns / 8 + 16, nx + nx / 8 + 16);
     if (rc != DTK_OK) return rc;
-    rc = launch_compact2(b);
+    rc = launch_compact2(b, 3);
     if (rc != DTK_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(b->h_totals + 7, b->d_totals + 7, 8, hipMemcpyDeviceToHost, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
+  }
+  // documents with EOT calls that the first compaction kernel left alone
+  {
+    const bool eot = (b->h_totals[7] >> 32) != 0;
+    if (eot && !b->ran_full) {
+      int rc = launch_compact2(b, 2);
+      if (rc != DTK_OK) return rc;
+      HIP_TRY(hipMemcpyAsync(b->h_totals + 7, b->d_totals + 7, 8, hipMemcpyDeviceToHost, b->stream));
+      HIP_TRY(hipStreamSynchronize(b->stream));
+    }
+    b->expect_eot = eot;
   }
   // documents whose calls are not in position order (ST_IRREGULAR): their rows come from the exact pass
   b->h_exact_ids.clear(); b->h_exact_off.assign(1, 0); b->h_calls.clear();

@@ -196,6 +196,7 @@ struct DtkCompactArgs {
   struct DtkSegIn *seg_in;                // k_seg_scan: the carries a segment starts with
   uint32_t *doc_seq;                      // k_seg_scan: 1 = this long document must be compacted sequentially
   uint32_t *any_irregular;                // set to 1 if a document is flagged ST_IRREGULAR (the host then runs the exact pass)
+  uint32_t *any_eot;                      // set to 1 by k_compact<false> if a document is left to k_compact<true>
   const uint32_t *skip_if;                // documents still to repair: the pass does nothing unless this is 0 (null: run)
 };
 
@@ -279,7 +280,7 @@ int dtk_launch_spec(const struct DtkTableDev *tab, const struct DtkWalkArgs *arg
                     uint32_t *n_bad, void *stream);
 int dtk_launch_redo_clear(const struct DtkWalkArgs *args, const struct DtkSpecArgs *spec, void *stream);
 int dtk_launch_compact(const struct DtkCompactArgs *args, uint32_t small_max, const uint32_t *big_docs, uint32_t n_big,
-                       void *stream);
+                       int which, void *stream);
 int dtk_launch_exact(const struct DtkTableDev *tab, const struct DtkExactArgs *args, void *stream);
 int dtk_launch_seg_prepare(const struct DtkCompactArgs *args, const uint32_t *doc_seg0, void *stream);
 int dtk_launch_render(const struct DtkRenderArgs *args, int stage, void *stream);

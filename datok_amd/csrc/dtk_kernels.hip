@@ -1745,9 +1745,17 @@ __device__ __forceinline__ uint32_t lowmask(uint32_t n) { return n >= 32u ? 0xFF
 // tracks (token_writer.go:38-42: posC, pos, sentB, sent) is recovered with ballots, popcounts of the lanes
 // below and a handful of shuffles; wave-uniform carries link the rounds.  Order of the calls at one position =
 // bit order of the queued flags.
+//
+// Two kernels share the text below.  FULL = false: the documents without an EOT call -- tokens and epsilon SentenceEnds
+// only, every tile takes the fast path; none of the queue, of the heavy rounds or of their carries is compiled in
+// (about half the registers, a third of the code).  FULL = true: the documents with one.  Which is which follows from
+// what the walk counted: a document has an EOT call iff it has more than one TextEnd or its only TextEnd is not the
+// tail's.  The first kernel tells the host that the second is needed (any_eot); a batch object whose last run
+// needed it launches it right away (dtk_host.cpp).
+template <bool FULL>
 __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A, uint32_t small_max, const uint32_t *big_docs) {
-  __shared__ uint32_t qpos[CQ_CAP], qrn[CQ_CAP], qst[CQ_CAP], qsr[CQ_CAP];
-  __shared__ uint8_t qfl[CQ_CAP];
+  __shared__ uint32_t qpos[FULL ? CQ_CAP : 1u], qrn[FULL ? CQ_CAP : 1u], qst[FULL ? CQ_CAP : 1u], qsr[FULL ? CQ_CAP : 1u];
+  __shared__ uint8_t qfl[FULL ? CQ_CAP : 1u];
   const bool seg_mode = A.seg_doc != nullptr;
   if (A.skip_if && *A.skip_if != 0u) return;  // documents are still to be repaired: the host runs this pass afterwards
   // one wave per segment, per document, or per document of the list of those that k_compact_small leaves to me
@@ -1777,6 +1785,13 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A, uint32_t sma
   if (A.totals[0] > A.tok_cap || A.totals[1] > A.sent_cap || A.totals[2] > A.text_cap) return;
   const uint64_t tok_base = A.tok_off[d], sent_base = A.sent_off[d], text_base = A.text_off[d];
   const uint64_t tok_lim = A.tok_off[d + 1], sent_lim = A.sent_off[d + 1], text_lim = A.text_off[d + 1];
+  {
+    const bool has_eot = text_lim - text_base != 1ull || !(A.doc_tail[d] & DTK_TAIL_E);
+    if (has_eot != FULL) {
+      if (!FULL && lane == 0) atomicOr(A.any_eot, 1u);
+      return;
+    }
+  }
 
   // wave-uniform carries
   uint32_t cR = 0;           // runes started before the tile
@@ -2012,8 +2027,9 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A, uint32_t sma
     uint32_t pS = __shfl_up(wS, 1), pR = __shfl_up(wR, 1), pRb = __shfl_up(rB, 1);
     if (lane == 0) { pS = pS_in; pR = pR_in; pRb = pRb_in; }
     const bool any_eot = __ballot((wT | wU) != 0u) != 0ull;  // wave-uniform: most tiles hold no EOT
+    if (!FULL && any_eot) status |= ST_INTERNAL;  // (the counts said there is none: the exact pass decides)
 
-    if (!any_eot) {
+    if (!FULL || !any_eot) {
       // ---- fast: no EOT call in the tile, so the only calls are Token (END) and the epsilon SentenceEnd (SEPS) and
       //      every lane can work through its own 32 positions: no queue.  What crosses lanes comes from three wave
       //      scans (tokens, SentenceEnd calls, sentence ints) and a carry chain over two ballots: "is a sentence
@@ -2118,7 +2134,7 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A, uint32_t sma
       cTE += tot2 & 0xFFFFu;
       cNSev += tot2 >> 16;
       cNSent += totS;
-    } else {
+    } else if constexpr (FULL) {
       for (uint32_t step = 0; step < 8u; step++) {
         const uint32_t S0 = T0 + 256u * step;  // first position of the step (wave-uniform)
         if (S0 >= n_pos) break;
@@ -2631,13 +2647,17 @@ extern "C" int dtk_launch_exact(const DtkTableDev *tab, const DtkExactArgs *args
 
 // small_max: documents of at most that many bytes are compacted by one lane each (k_compact_small; 0: none);
 // big_docs / n_big: the other documents (the wave-per-document grid then covers only those; segment mode: all segments)
+// which: 1 the documents without an EOT call (and the lane-per-document kernel), 2 the documents with one, 3 both
 extern "C" int dtk_launch_compact(const DtkCompactArgs *args, uint32_t small_max, const uint32_t *big_docs, uint32_t n_big,
-                                  void *stream) {
+                                  int which, void *stream) {
   if (args->n_docs == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  if (small_max) hipLaunchKernelGGL(k_compact_small, dim3((args->n_docs + 255u) / 256u), dim3(256), 0, s, *args, small_max);
+  if (small_max && (which & 1))
+    hipLaunchKernelGGL(k_compact_small, dim3((args->n_docs + 255u) / 256u), dim3(256), 0, s, *args, small_max);
   const uint32_t grid = args->seg_doc ? args->n_segs : (small_max ? n_big : args->n_docs);
-  if (grid) hipLaunchKernelGGL(k_compact, dim3(grid), dim3(WAVE), 0, s, *args, small_max, args->seg_doc ? nullptr : (small_max ? big_docs : nullptr));
+  const uint32_t *list = args->seg_doc ? nullptr : (small_max ? big_docs : nullptr);
+  if (grid && (which & 1)) hipLaunchKernelGGL(k_compact<false>, dim3(grid), dim3(WAVE), 0, s, *args, small_max, list);
+  if (grid && (which & 2)) hipLaunchKernelGGL(k_compact<true>, dim3(grid), dim3(WAVE), 0, s, *args, small_max, list);
   return (int)hipGetLastError();
 }
 
