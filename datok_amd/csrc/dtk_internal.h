@@ -196,7 +196,7 @@ struct DtkCompactArgs {
   struct DtkSegIn *seg_in;                // k_seg_scan: the carries a segment starts with
   uint32_t *doc_seq;                      // k_seg_scan: 1 = this long document must be compacted sequentially
   uint32_t *any_irregular;                // set to 1 if a document is flagged ST_IRREGULAR (the host then runs the exact pass)
-  uint32_t *any_eot;                      // set to 1 by k_compact<false> if a document is left to k_compact<true>
+  uint32_t *any_eot;                      // set to 1 by k_compact_plain if a document is left to k_compact_eot
   const uint32_t *skip_if;                // documents still to repair: the pass does nothing unless this is 0 (null: run)
 };
 

@@ -1753,7 +1753,7 @@ __device__ __forceinline__ uint32_t lowmask(uint32_t n) { return n >= 32u ? 0xFF
 // tail's.  The first kernel tells the host that the second is needed (any_eot); a batch object whose last run
 // needed it launches it right away (dtk_host.cpp).
 template <bool FULL>
-__global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A, uint32_t small_max, const uint32_t *big_docs) {
+__device__ __forceinline__ void compact_unit(const DtkCompactArgs &A, uint32_t small_max, const uint32_t *big_docs) {
   __shared__ uint32_t qpos[FULL ? CQ_CAP : 1u], qrn[FULL ? CQ_CAP : 1u], qst[FULL ? CQ_CAP : 1u], qsr[FULL ? CQ_CAP : 1u];
   __shared__ uint8_t qfl[FULL ? CQ_CAP : 1u];
   const bool seg_mode = A.seg_doc != nullptr;
@@ -2245,6 +2245,15 @@ __global__ __launch_bounds__(WAVE) void k_compact(DtkCompactArgs A, uint32_t sma
   }
 }
 
+// (69 VGPRs.  Forced down to 64 for eight waves per SIMD the compiler spills four of them: slower, 22.6 -> 25.1 us per
+//  16 MiB on a saturated chip)
+__global__ __launch_bounds__(WAVE) void k_compact_plain(DtkCompactArgs A, uint32_t small_max, const uint32_t *big_docs) {
+  compact_unit<false>(A, small_max, big_docs);
+}
+__global__ __launch_bounds__(WAVE) void k_compact_eot(DtkCompactArgs A, uint32_t small_max, const uint32_t *big_docs) {
+  compact_unit<true>(A, small_max, big_docs);
+}
+
 // ---- small documents: one LANE per document.
 // A wave per document spends most of its instructions on cross-lane bookkeeping; for a batch of many small documents
 // (tens of thousands of tweets or sentences) that is two orders of magnitude more work than the documents hold.
@@ -2656,8 +2665,8 @@ extern "C" int dtk_launch_compact(const DtkCompactArgs *args, uint32_t small_max
     hipLaunchKernelGGL(k_compact_small, dim3((args->n_docs + 255u) / 256u), dim3(256), 0, s, *args, small_max);
   const uint32_t grid = args->seg_doc ? args->n_segs : (small_max ? n_big : args->n_docs);
   const uint32_t *list = args->seg_doc ? nullptr : (small_max ? big_docs : nullptr);
-  if (grid && (which & 1)) hipLaunchKernelGGL(k_compact<false>, dim3(grid), dim3(WAVE), 0, s, *args, small_max, list);
-  if (grid && (which & 2)) hipLaunchKernelGGL(k_compact<true>, dim3(grid), dim3(WAVE), 0, s, *args, small_max, list);
+  if (grid && (which & 1)) hipLaunchKernelGGL(k_compact_plain, dim3(grid), dim3(WAVE), 0, s, *args, small_max, list);
+  if (grid && (which & 2)) hipLaunchKernelGGL(k_compact_eot, dim3(grid), dim3(WAVE), 0, s, *args, small_max, list);
   return (int)hipGetLastError();
 }
 
