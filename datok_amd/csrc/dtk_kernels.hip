@@ -243,26 +243,25 @@ __global__ __launch_bounds__(SYM_THREADS) void k_symbolize(const uint8_t *__rest
           bb[k] = in ? (uint32_t)sb[(int)pos + o] : 0u;
         }
         const uint32_t b0 = bb[3], b1 = bb[4], b2 = bb[5], b3 = bb[6];
-        const uint32_t wd = go_width(b0, b1, b2, b3, avail);
+        // One width decides everything.  A non-continuation byte starts a rune of go_width(b0 ..) bytes.  A
+        // continuation byte starts one (U+FFFD, one byte) unless the nearest non-continuation byte within the previous
+        // 3 of the same document begins a valid sequence that reaches it: the width of THAT sequence is the question.
+        const uint32_t n1 = (uint32_t)((bb[2] & 0xC0u) != 0x80u), n2 = (uint32_t)((bb[1] & 0xC0u) != 0x80u),
+                       n3 = (uint32_t)((bb[0] & 0xC0u) != 0x80u);
+        const uint32_t in1 = (uint32_t)(back >= 1u), in2 = (uint32_t)(back >= 2u), in3 = (uint32_t)(back >= 3u);
+        const uint32_t cont = (uint32_t)((b0 & 0xC0u) == 0x80u);
+        const uint32_t k1 = cont & in1 & n1, k2 = cont & in2 & (n1 ^ 1u) & n2, k3 = cont & in3 & (n1 ^ 1u) & (n2 ^ 1u) & n3;
+        const uint32_t k = k1 + 2u * k2 + 3u * k3;  // distance to that byte; 0: none (or b0 is no continuation byte)
+        const uint32_t c0 = k3 ? bb[0] : (k2 ? bb[1] : (k1 ? bb[2] : b0)), c1 = k3 ? bb[1] : (k2 ? bb[2] : (k1 ? b0 : b1));
+        const uint32_t c2 = k3 ? bb[2] : (k2 ? b0 : (k1 ? b1 : b2)), c3 = k3 ? b0 : (k2 ? b1 : (k1 ? b2 : b3));
+        const uint32_t wseq = go_width(c0, c1, c2, c3, avail + k);
+        const uint32_t start = k ? (uint32_t)(wseq <= k) : 1u;
+        const uint32_t wd = cont ? 1u : wseq;  // a continuation byte that starts a rune is invalid on its own
         // rune value for the decoded width (U+FFFD for an invalid byte; b0 >= 0x80 here)
         const uint32_t r2 = ((b0 & 0x1Fu) << 6) | (b1 & 0x3Fu);
         const uint32_t r3 = ((b0 & 0x0Fu) << 12) | ((b1 & 0x3Fu) << 6) | (b2 & 0x3Fu);
         const uint32_t r4 = ((b0 & 0x07u) << 18) | ((b1 & 0x3Fu) << 12) | ((b2 & 0x3Fu) << 6) | (b3 & 0x3Fu);
         const uint32_t rune = wd == 1 ? 0xFFFDu : (wd == 2 ? r2 : (wd == 3 ? r3 : r4));
-        // does this byte start a rune?  a non-continuation byte always does; a
-        // continuation byte does unless the nearest non-continuation byte within the
-        // previous 3 (same document) begins a valid sequence that reaches it.
-        uint32_t start = 1, open = (b0 & 0xC0u) == 0x80u;  // open: still looking
-#pragma unroll
-        for (int k = 1; k <= 3; k++) {
-          const uint32_t l0 = bb[3 - k];
-          const uint32_t noncont = (l0 & 0xC0u) != 0x80u;
-          const uint32_t inside = (uint32_t)k <= back;
-          const uint32_t w2 = go_width(l0, bb[4 - k], bb[5 - k], bb[6 - k], avail + (uint32_t)k);
-          const uint32_t cand = open & inside & noncont;
-          start = cand ? (uint32_t)(w2 <= (uint32_t)k) : start;
-          open = open & inside & (noncont ^ 1u);
-        }
         uint32_t a_cls;
         if (rune < 256u) {
           a_cls = lat[rune];
