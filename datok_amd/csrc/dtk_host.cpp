@@ -1216,11 +1216,8 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
     fix_in_scan = b->n_docs <= 8192u && b->dev_rounds == 0;  // k_spec_fix's step rides in the one-block scan kernel
     for (int stage = 0; stage < 5; stage++) {
       if (((skip & 2) && stage <= 1) || ((skip & 4) && stage == 2) || (stage == 4 && fix_in_scan)) { STAGE(3 + stage); continue; }
-      // one launch for start records + walk (timed as "walk"); the link pass, which only reads the
-      // records, then runs in front of the verification
-      const int what = split ? stage : (stage <= 1 ? -1 : stage == 2 ? 6 : stage);
-      if (!split && stage == 3 && dtk_launch_spec(&m->tab, &w, &sp, 1, cmp_mask_of(m), b->d_redo, nb, s))
-        return hip_fail(hipGetLastError(), "speculative walk");
+      // one launch for start records + walk (timed as "walk"), one for link + verify
+      const int what = split ? stage : (stage <= 1 ? -1 : stage == 2 ? 6 : stage == 3 ? 7 : stage);
       if (what >= 0 && dtk_launch_spec(&m->tab, &w, &sp, what, cmp_mask_of(m), b->d_redo, nb, s))
         return hip_fail(hipGetLastError(), "speculative walk");
       STAGE(3 + stage);  // ends: start records, link, chunk walk, verify, fix (split) / -, -, start + walk, link + verify, fix

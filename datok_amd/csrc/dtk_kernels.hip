@@ -1537,7 +1537,14 @@ __global__ __launch_bounds__(WAVE) void k_spec_walk(TRANS tr, DtkWalkArgs A, Dtk
 // One thread per lane: did I arrive exactly at my successor's record (position,
 // state, flags)?  Lanes that did add their counts / status to the document; the
 // first lane that did not is recorded (bit-inverted, zero = none) in fail_lane[d].
-__global__ __launch_bounds__(256) void k_spec_verify(DtkWalkArgs A, DtkSpecArgs S, uint32_t cmp_mask) {
+//
+// local_link (the first pass, where every lane with a record has walked to the first sync point behind its own chunk):
+// the lane decides from its own and its successor's record what k_spec_link + first_bad[d] decide otherwise -- one
+// launch and a round of atomics less.  A lane with a record either has a successor record at or behind its own (then it
+// must have arrived exactly there) or it is the chain's last lane (then it must have reached EOF, and no later lane
+// may have a record: the lane in front of such a record, which has none itself, finds the chain's last lane by
+// walking back).  The first lane that fails is the same one in both formulations.
+__global__ __launch_bounds__(256) void k_spec_verify(DtkWalkArgs A, DtkSpecArgs S, uint32_t cmp_mask, uint32_t local_link) {
   if (S.go && *S.go == 0u) return;
   const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
   bool live = L < S.n_lanes;  // every lane stays for the wave reduction below
@@ -1547,7 +1554,33 @@ __global__ __launch_bounds__(256) void k_spec_verify(DtkWalkArgs A, DtkSpecArgs 
     d = S.lane_doc[L];
     if (S.redo_from && S.redo_from[d] == 0xFFFFFFFFu) { live = false; d = 0xFFFFFFFFu; }  // a repair round: not this document
   }
-  if (live) {
+  if (live && local_link) {
+    const uint32_t L0 = S.chunk_off[d], L1 = S.chunk_off[d + 1];
+    const bool has_next = L + 1u < L1;
+    const DtkLaneState own = S.lane_start[L], en = S.lane_end[L];
+    DtkLaneState nx{0xFFFFFFFFu, 0u, 0u, 0u};
+    if (has_next) nx = S.lane_start[L + 1];
+    uint32_t link_ok = 1u;
+    if (own.p == 0xFFFFFFFFu) {
+      // behind the chain: legitimate only if the chain ran to EOF and no later lane found a sync point
+      if (nx.p != 0xFFFFFFFFu) {
+        uint32_t x = L - 1u;  // (lane 0 of a document always has a record)
+        while (x > L0 && S.lane_start[x].p == 0xFFFFFFFFu) x--;
+        atomicMax(&S.fail_lane[d], ~x);
+      }
+    } else {
+      bool good;
+      if (nx.p != 0xFFFFFFFFu && nx.p >= own.p) {
+        good = en.p == nx.p && en.t == nx.t && ((en.flags ^ nx.flags) & cmp_mask) == 0 && !(en.flags & LANE_F_DROPPED);
+      } else {
+        // the chain's last lane must reach EOF (a successor record before my own breaks the chain right here)
+        good = nx.p == 0xFFFFFFFFu && en.p == 0xFFFFFFFFu && !(en.flags & LANE_F_IDLE);
+      }
+      if (good) c = S.lane_cnt[L]; else atomicMax(&S.fail_lane[d], ~L);
+      link_ok = good ? 1u : 0u;
+    }
+    S.lane_plan[L].pad = link_ok;
+  } else if (live) {
     const uint32_t L0 = S.chunk_off[d];
     const uint32_t k = L - L0, fb = ~S.first_bad[d];
     uint32_t link_ok = 1u;  // did I arrive exactly at my successor's record (k_redo_spread reads it)
@@ -2472,11 +2505,28 @@ __global__ __launch_bounds__(1024) void k_scan3(const uint64_t *ca, const uint64
   const uint32_t hi = lo + per < n ? lo + per : n;
   uint64_t sa = 0, sb = 0, sc = 0;
   uint32_t fl = 0;
-  for (uint32_t i = lo; i < hi; i++) {
-    sa += ca[i]; sb += cb[i]; sc += cc[i]; fl += status[i] != 0;
-    if (fix) {
-      const uint32_t bad = ~S.fail_lane[i];
-      if (bad == 0xFFFFFFFFu) redo_out[i] = 0xFFFFFFFFu; else mark_redo(S, i, bad, redo_out, n_bad);
+  // four documents at a time: their loads first, one wait -- a loop of dependent round trips was most of this kernel's
+  // 15 us.  (Not all eight of a thread in registers: a 1024-thread block with 100 VGPRs per lane has to wait for a
+  // whole CU to drain while other batches' walks fill the chip -- three batches in flight lost 10 %.)
+  constexpr uint32_t G = 4u;
+  for (uint32_t i0 = lo; i0 < hi; i0 += G) {
+    uint64_t va[G], vb[G], vc[G];
+    uint32_t vs[G], vf[G];
+#pragma unroll
+    for (uint32_t j = 0; j < G; j++) {
+      const uint32_t i = i0 + j;
+      const bool ok = i < hi;
+      va[j] = ok ? ca[i] : 0ull; vb[j] = ok ? cb[i] : 0ull; vc[j] = ok ? cc[i] : 0ull;
+      vs[j] = ok ? status[i] : 0u;
+      vf[j] = (ok && fix) ? S.fail_lane[i] : 0u;
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < G; j++) {
+      sa += va[j]; sb += vb[j]; sc += vc[j]; fl += vs[j] != 0u;
+      if (fix && i0 + j < hi) {
+        const uint32_t bad = ~vf[j];
+        if (bad == 0xFFFFFFFFu) redo_out[i0 + j] = 0xFFFFFFFFu; else mark_redo(S, i0 + j, bad, redo_out, n_bad);
+      }
     }
   }
   uint64_t xa = sa, xb = sb, xc = sc;
@@ -2493,9 +2543,20 @@ __global__ __launch_bounds__(1024) void k_scan3(const uint64_t *ca, const uint64
   uint32_t bf = 0;
   for (uint32_t w = 0; w < wid; w++) { ba += wsum[0][w]; bb += wsum[1][w]; bc += wsum[2][w]; bf += wfl[w]; }
   uint64_t ra = ba + xa - sa, rb = bb + xb - sb, rc = bc + xc - sc;
-  for (uint32_t i = lo; i < hi; i++) {
-    a[i] = ra; b[i] = rb; c[i] = rc;
-    ra += ca[i]; rb += cb[i]; rc += cc[i];
+  for (uint32_t i0 = lo; i0 < hi; i0 += G) {
+    uint64_t va[G], vb[G], vc[G];
+#pragma unroll
+    for (uint32_t j = 0; j < G; j++) {
+      const uint32_t i = i0 + j;
+      const bool ok = i < hi;
+      va[j] = ok ? ca[i] : 0ull; vb[j] = ok ? cb[i] : 0ull; vc[j] = ok ? cc[i] : 0ull;
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < G; j++) {
+      const uint32_t i = i0 + j;
+      if (i < hi) { a[i] = ra; b[i] = rb; c[i] = rc; }
+      ra += va[j]; rb += vb[j]; rc += vc[j];
+    }
   }
   if (tid == T - 1) {
     a[n] = ba + xa; b[n] = bb + xb; c[n] = bc + xc;
@@ -2581,7 +2642,7 @@ extern "C" int dtk_launch_walk(const DtkTableDev *tab, const DtkWalkArgs *args, 
   });
 }
 
-// stage: 6 start records + walk, 1 link, 3 verify, 4 fix (first pass; or 0 start records, 1, 2 walk, 3, 4);
+// stage: 6 start records + walk, 7 link + verify, 4 fix (first pass; or 0 start records, 1 link, 2 walk, 3 verify, 4);
 //        5 clear, 6 plan, 2 walk, 7 check (repair rounds, spec->redo_from set)
 extern "C" int dtk_launch_spec(const DtkTableDev *tab, const DtkWalkArgs *args, const DtkSpecArgs *spec,
                                int stage, uint32_t cmp_mask, uint32_t *redo_out, uint32_t *n_bad,
@@ -2616,7 +2677,10 @@ extern "C" int dtk_launch_spec(const DtkTableDev *tab, const DtkWalkArgs *args, 
                            tab->identity);
       });
     case 3:
-      hipLaunchKernelGGL(k_spec_verify, dim3(lane_blocks256), dim3(256), 0, s, *args, *spec, cmp_mask);
+      hipLaunchKernelGGL(k_spec_verify, dim3(lane_blocks256), dim3(256), 0, s, *args, *spec, cmp_mask, 0u);
+      return (int)hipGetLastError();
+    case 7:  // first pass behind k_spec_both: link + verify in one
+      hipLaunchKernelGGL(k_spec_verify, dim3(lane_blocks256), dim3(256), 0, s, *args, *spec, cmp_mask, 1u);
       return (int)hipGetLastError();
     case 4:
       hipLaunchKernelGGL(k_spec_fix, dim3(doc_blocks), dim3(256), 0, s, *args, *spec, redo_out, n_bad);
