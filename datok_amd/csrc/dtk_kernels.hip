@@ -102,7 +102,19 @@ __global__ __launch_bounds__(SYM_THREADS) void k_symbolize(const uint8_t *__rest
                                                     const uint32_t *__restrict__ blk_doc,
                                                     unsigned long long *__restrict__ n_invalid,
                                                     uint32_t *__restrict__ rs_bits,
-                                                    uint32_t *__restrict__ ev_bits, uint32_t bit_words) {
+                                                    uint32_t *__restrict__ ev_bits, uint32_t bit_words,
+                                                    uint4 *__restrict__ acc, uint32_t acc16) {
+  // The run's accumulator block (totals, per-document counts, status and check words; dtk_batch_run) starts from
+  // zero: the first blocks clear it here instead of a launch of its own in front (7 us of a batch's 230).  All but
+  // totals[6], the count of invalid bytes, which blocks of this very launch add to: it only ever grows and the host
+  // takes differences.
+  if (acc) {
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (uint32_t i = blockIdx.x * SYM_THREADS + threadIdx.x; i < acc16; i += gridDim.x * SYM_THREADS) {
+      if (i == 3u) reinterpret_cast<unsigned long long *>(acc)[7] = 0ull;  // totals[7]; totals[6] stays
+      else acc[i] = z;
+    }
+  }
   __shared__ uint32_t s_rs[SYM_BLOCK_BYTES / 32];  // bit i: byte i of the block starts a rune
   __shared__ uint16_t lut[128];       // symbol | class | width 1 for the runes < 128 (index = byte)
   __shared__ uint16_t lat[256];       // symbol | class for runes < 256 (heavy path, Latin-1)
@@ -2591,17 +2603,17 @@ extern "C" int dtk_launch_clear2(void *a, uint64_t a_bytes, void *b, uint64_t b_
 extern "C" int dtk_launch_symbolize(const uint8_t *text, const uint64_t *doc_off, uint32_t n_docs,
                                     uint64_t total, const DtkSigmaDev *sig, uint16_t *sym, int padded,
                                     const uint32_t *blk_doc, unsigned long long *n_invalid, uint32_t *rs_bits,
-                                    uint32_t *ev_bits, uint32_t bit_words, void *stream) {
+                                    uint32_t *ev_bits, uint32_t bit_words, void *acc, uint64_t acc_bytes, void *stream) {
   if (total == 0 || n_docs == 0) return 0;
   const uint32_t blocks = (uint32_t)((total + SYM_BLOCK_BYTES - 1) / SYM_BLOCK_BYTES);
   // ALIGNED4 may read up to 3 bytes past `total`: true for the batch's own (padded) buffer;
   // a caller-owned device buffer only qualifies when its size is a multiple of 4
   if ((((uintptr_t)text) & 3u) == 0 && (padded || (total & 3u) == 0))
     hipLaunchKernelGGL(k_symbolize<true>, dim3(blocks), dim3(SYM_THREADS), 0, (hipStream_t)stream, text, doc_off, n_docs,
-                       total, *sig, sym, blk_doc, n_invalid, rs_bits, ev_bits, bit_words);
+                       total, *sig, sym, blk_doc, n_invalid, rs_bits, ev_bits, bit_words, (uint4 *)acc, (uint32_t)(acc_bytes / 16));
   else
     hipLaunchKernelGGL(k_symbolize<false>, dim3(blocks), dim3(SYM_THREADS), 0, (hipStream_t)stream, text, doc_off, n_docs,
-                       total, *sig, sym, blk_doc, n_invalid, rs_bits, ev_bits, bit_words);
+                       total, *sig, sym, blk_doc, n_invalid, rs_bits, ev_bits, bit_words, (uint4 *)acc, (uint32_t)(acc_bytes / 16));
   return (int)hipGetLastError();
 }
 
