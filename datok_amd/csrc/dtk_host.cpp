@@ -64,6 +64,7 @@ struct dtk_model {
   int kind = 0;
   int epsilon = 0, unknown = 0, identity = 0, final_state = 0, sigma_count = 0;
   uint32_t state_count = 0;
+  uint32_t dense_states = 0;   // double array laid out as a matrix (densify in build_datok): its states; 0: the pairs are walked
   uint64_t array_len = 0;
   uint32_t n_eps_states = 0, max_eps_chain = 0, unknown_used = 0;
   uint64_t device_bytes = 0;
@@ -203,7 +204,7 @@ static bool special_ids_ok(const dtk_model *m) {
          (m->identity != m->unknown || m->identity < 0) && m->epsilon != m->identity;
 }
 
-static int layout_matrix(dtk_model *m, const std::vector<uint32_t> &arr);
+static int layout_matrix(dtk_model *m, const std::vector<uint32_t> &arr, uint64_t n_states, bool da_dense);
 
 // ParseMatrix (matrix.go:235-337)
 static int build_matrix(dtk_model *m, const std::vector<uint8_t> &raw) {
@@ -224,13 +225,14 @@ static int build_matrix(dtk_model *m, const std::vector<uint8_t> &raw) {
   if (!special_ids_ok(m) || m->state_count == 0 || m->state_count >= 0x7FFFFFFFu) return DTK_E_MODEL;
   std::vector<uint32_t> arr(m->array_len);
   for (uint64_t x = 0; x < m->array_len; x++) arr[x] = rd32(raw.data() + off + x * 4);
-  return layout_matrix(m, arr);
+  return layout_matrix(m, arr, m->state_count, false);
 }
 
 // Device layout of a matrix tokenizer whose header fields and sigma are set in `m` and whose
 // symbol-major array (matrix.go:463) is `arr`.
-static int layout_matrix(dtk_model *m, const std::vector<uint32_t> &arr) {
-  const uint64_t N = m->state_count, S = (uint64_t)m->sigma_count;
+// (n_states / da_dense: the same layout for the transitions of a double-array tokenizer, see densify_datok)
+static int layout_matrix(dtk_model *m, const std::vector<uint32_t> &arr, uint64_t n_states, bool da_dense) {
+  const uint64_t N = n_states, S = (uint64_t)m->sigma_count;
   auto cell = [&](uint64_t a, uint64_t t) -> uint32_t {  // array[(a-1)*stateCount + t], matrix.go:463
     return arr[(a - 1) * N + t];
   };
@@ -310,6 +312,7 @@ static int layout_matrix(dtk_model *m, const std::vector<uint32_t> &arr) {
   m->tab.fused = fused ? 1u : 0u;
   m->tab.ident_guard = m->unknown_used ? (uint32_t)m->identity : 0xFFFFFFFFu;
   m->tab.plain_walk = getenv("DATOK_PLAIN_WALK") ? 1u : 0u;
+  m->tab.da_dense = da_dense ? 1u : 0u;
   m->tab.stride = stride;
   m->tab.n_states = (uint32_t)N;
   m->tab.n_eps = m->n_eps_states;
@@ -373,6 +376,64 @@ static int build_datok(dtk_model *m, const std::vector<uint8_t> &raw) {
     if (par && par < L && (uint64_t)(bc[2 * par] & DTK_RESTBIT) + (uint32_t)m->unknown == i) {
       m->unknown_used = 1;
       break;
+    }
+  }
+  // The double array is a compressed encoding of the same kind of automaton the matrix holds dense: a shipped
+  // model has some 20 000 states hidden in its 2.9 million pairs.  If they fit the fused cells (15-bit state ids),
+  // the device walks them as a matrix -- one load per step instead of two dependent ones, the lean loop, fused
+  // epsilon cells -- under the double array's own rules for EOT (datok.go:1019-1030; walk_fused<.., IS_MATRIX =
+  // false>, compaction and replay go by m->kind).  DATOK_NO_DENSE=1 keeps the pairs (DaTrans; what the tests of that
+  // path set).
+  if (!getenv("DATOK_NO_DENSE")) {
+    std::vector<uint32_t> arr;
+    uint64_t n_dense = 0;
+    // one step of datok.go:888-901 + 1055-1063 from state s0 on symbol a: 0 = no arc, else target | FIRSTBIT if
+    // non-token; false = an access the reference would panic on (no dense form for such a file)
+    auto step = [&](uint64_t s0, uint32_t a, uint32_t &out) -> bool {
+      out = 0;
+      const uint64_t idx = (uint64_t)(bc[2 * s0] & DTK_RESTBIT) + a;
+      if (idx > size) return true;         // datok.go:889: t > check(1) fails before the array is touched
+      if (idx >= L) return false;
+      if ((bc[2 * idx + 1] & DTK_RESTBIT) != s0) return true;
+      uint64_t t = idx;
+      if (bc[2 * idx] & DTK_FIRSTBIT) {    // separate: the representative
+        t = bc[2 * idx] & DTK_RESTBIT;
+        if (t >= L || t == 0) return false;
+      }
+      out = (uint32_t)t | ((bc[2 * idx + 1] & DTK_FIRSTBIT) ? DTK_FIRSTBIT : 0u);
+      return true;
+    };
+    bool ok = true;
+    std::vector<uint32_t> id(L, 0);        // double-array index -> dense state number (1 = start)
+    std::vector<uint64_t> order{0, 1};     // dense state number -> index
+    id[1] = 1;
+    const uint32_t S = (uint32_t)m->sigma_count;
+    std::vector<uint32_t> trans;           // state-major while the states are being discovered
+    for (uint64_t q = 1; ok && q < order.size(); q++) {
+      const uint64_t s0 = order[q];
+      uint32_t x;
+      ok = step(s0, 0u, x) && x == 0u;     // symbol 0 must have no arc (the matrix's column 0, matrix.go:459)
+      for (uint32_t a = 1; ok && a < S; a++) {
+        ok = step(s0, a, x);
+        const uint64_t t = x & ~DTK_FIRSTBIT;
+        if (ok && t != 0 && id[t] == 0) {
+          id[t] = (uint32_t)order.size();
+          order.push_back(t);
+          ok = order.size() <= 0x7FFFu;    // the fused cells' 15-bit state ids
+        }
+        trans.push_back(ok && t != 0 ? (id[t] | (x & DTK_FIRSTBIT)) : 0u);
+      }
+    }
+    if (ok) {
+      n_dense = order.size() - 1;
+      arr.assign((size_t)(S - 1) * n_dense + n_dense + 1, 0);  // array[(a-1)*N + t], t in 1..N (matrix.go:463)
+      for (uint64_t q = 1; q <= n_dense; q++)
+        for (uint32_t a = 1; a < S; a++) arr[(size_t)(a - 1) * n_dense + q] = trans[(size_t)(q - 1) * (S - 1) + (a - 1)];
+      const uint32_t keep_states = m->state_count;
+      const int rc = layout_matrix(m, arr, n_dense, true);
+      m->state_count = keep_states;
+      m->dense_states = (uint32_t)n_dense;
+      return rc;
     }
   }
   std::vector<uint32_t> dev(L * 2);
@@ -572,7 +633,7 @@ static int foma_to_matrix(dtk_model *m, const std::vector<uint8_t> &raw, std::ve
 static int build_foma(dtk_model *m, const std::vector<uint8_t> &raw) {
   std::vector<uint32_t> arr;
   int rc = foma_to_matrix(m, raw, arr);
-  return rc != DTK_OK ? rc : layout_matrix(m, arr);
+  return rc != DTK_OK ? rc : layout_matrix(m, arr, m->state_count, false);
 }
 
 static void put_rune(std::vector<uint8_t> &o, uint32_t r) {  // bufio.Writer.WriteRune
@@ -681,6 +742,7 @@ extern "C" int dtk_model_get_info(const dtk_model *m, dtk_model_info *o) {
   o->final_state = m->final_state; o->sigma_count = m->sigma_count; o->state_count = m->state_count;
   o->array_len = m->array_len; o->n_eps_states = m->n_eps_states; o->max_eps_chain = m->max_eps_chain;
   o->entry_bytes = m->tab.entry_bytes; o->device_bytes = m->device_bytes; o->unknown_used = m->unknown_used;
+  o->dense_states = m->dense_states;
   return DTK_OK;
 }
 

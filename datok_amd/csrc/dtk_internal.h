@@ -91,6 +91,7 @@ struct DtkTableDev {
   uint32_t fused;        // matrix: uint32 cells with fused epsilon+rune entries (see MatrixFusedTrans)
   uint32_t ident_guard;  // identity symbol if arcs on `unknown` exist, else 0xFFFFFFFF
   uint32_t plain_walk;   // 1: always use the general walk loop (env DATOK_PLAIN_WALK, for A/B runs and tests)
+  uint32_t da_dense;     // 1: a double-array tokenizer whose transitions were laid out as a (fused) matrix at load
   uint32_t da_len;       // double array: pairs
   uint32_t da_size;      // array[1].check & RESTBIT (datok.go:333-335)
   uint32_t da_base1;     // device base word of index 1

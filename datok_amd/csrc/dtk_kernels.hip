@@ -808,7 +808,7 @@ extern "C" int dtk_probe_read(unsigned long long *out, int reset) {
 }
 #endif
 
-template <int MODE, bool FIRST = false>
+template <int MODE, bool FIRST = false, bool IS_MATRIX = true>
 __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uint16_t *__restrict__ sym_base,
                                            uint64_t off, uint32_t len, DtkLaneState init, uint32_t stop_pos,
                                            EventSink &sink, uint32_t epsilon, uint32_t cap, DtkLaneState &fin,
@@ -847,7 +847,7 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
       it++;                                                                                                   \
       if ((int32_t)x_ <= 0) { st |= ST_BAD_MODEL; done = true; break; }                                       \
       if (p > tp) { /* matrix.go:565-572 */                                                                   \
-        if (MODE != MODE_START) sink.template token<true>(bs, tp, p, ((F ^ 4u) & 7u) != 0);                   \
+        if (MODE != MODE_START) sink.template token<IS_MATRIX>(bs, tp, p, ((F ^ 4u) & 7u) != 0);                   \
         F = 12u;                                                                                              \
         if (hi - bs > DTK_WINDOW && count_runes(s, bs, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;            \
         tp = p; bs = p; eps_t = 0;                                                                            \
@@ -856,7 +856,7 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
           done = true;                                                                                        \
         }                                                                                                     \
       } else { /* matrix.go:573-576 */                                                                        \
-        if (MODE != MODE_START) sink.template sentence<true>(bs, p, (F & 8u) != 0);                           \
+        if (MODE != MODE_START) sink.template sentence<IS_MATRIX>(bs, p, (F & 8u) != 0);                           \
         F |= 1u;                                                                                              \
       }                                                                                                       \
       t = x_ & 0x7FFFu;                                                                                       \
@@ -935,8 +935,8 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
         if (flush && !beyond) sink.token_first(tp, p, ((F ^ 4u) & 7u) != 0);
         if (sentE && !beyond) sink.sentence_first(p, (F & 8u) != 0);
       } else {
-        if (flush) sink.template token<true>(bs, tp, p, ((F ^ 4u) & 7u) != 0);
-        if (sentE) sink.template sentence<true>(bs, p, (F & 8u) != 0);
+        if (flush) sink.template token<IS_MATRIX>(bs, tp, p, ((F ^ 4u) & 7u) != 0);
+        if (sentE) sink.template sentence<IS_MATRIX>(bs, p, (F & 8u) != 0);
       }
     }
     const uint32_t win = (DTK_KO & 2) ? 0u : hi - bs;   // bytes the window holds (before this iteration's rewind)
@@ -962,8 +962,8 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
     if (hardfail | eot_now | (beyond & (FIRST ? epsE : flush)) | (flush & (win > DTK_WINDOW)) | (win > DTK_WINDOW_BYTES) |
         (it > cap) | ((p >= len) & !backtrack)) {
       if (FIRST && MODE != MODE_START && beyond && !(DTK_KO & 1)) {  // what the common path left to this block
-        if (flush) sink.template token<true>(bs_old, tp_old, p_old, ((F_old ^ 4u) & 7u) != 0);
-        if (sentE) sink.template sentence<true>(bs_old, p_old, (F_old & 8u) != 0);
+        if (flush) sink.template token<IS_MATRIX>(bs_old, tp_old, p_old, ((F_old ^ 4u) & 7u) != 0);
+        if (sentE) sink.template sentence<IS_MATRIX>(bs_old, p_old, (F_old & 8u) != 0);
       }
       if (flush && win > DTK_WINDOW && count_runes(s, bs_old, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
       if (at_stop) {
@@ -978,7 +978,7 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
             if (p <= tp) { p = pn; }  // matrix.go:515-516
             if (p < tp) st |= ST_BAD_OFFSET;  // Token(bufft, buffer[:buffc]) with bufft > buffc
             e = p == pn ? e_next : e_cur;     // the rune at p (read again if it was not consumed)
-            if (MODE != MODE_START) sink.template token<true>(bs, tp, p, ((F ^ 4u) & 7u) != 0);
+            if (MODE != MODE_START) sink.template token<IS_MATRIX>(bs, tp, p, ((F ^ 4u) & 7u) != 0);
             F = 12u;
             if (hi - bs > DTK_WINDOW && count_runes(s, bs, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
             t = tr.start; eps_t = 0;
@@ -991,15 +991,17 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
           }
         }
         if (eot_now) {
-          if (MODE != MODE_START) sink.template eot<true>(bs, p, (F & 1u) == 0u, (F & 8u) != 0);
+          if (MODE != MODE_START) sink.template eot<IS_MATRIX>(bs, p, (F & 1u) == 0u, (F & 8u) != 0);
           F = (F & 4u) | 3u;  // sentenceEnd, textEnd; TextEnd: pos = pos[:0] (token_writer.go:158)
-          eps_t = 0;          // matrix.go:601 rewinds
-          if (hi - bs > DTK_WINDOW && count_runes(s, bs, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
-          tp = p; bs = p;
-          if (MODE != MODE_DOC && p >= stop_pos && !done) {
-            fin.p = p; fin.t = t; fin.aux = 0;
-            fin.flags = (F & 3u) | (init.flags & LANE_F_OK);
-            done = true;
+          if (IS_MATRIX) {    // matrix.go:601 rewinds; the double array keeps window and epsilon slot (datok.go:1019-1030)
+            eps_t = 0;
+            if (hi - bs > DTK_WINDOW && count_runes(s, bs, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
+            tp = p; bs = p;
+            if (MODE != MODE_DOC && p >= stop_pos && !done) {
+              fin.p = p; fin.t = t; fin.aux = 0;
+              fin.flags = (F & 3u) | (init.flags & LANE_F_OK);
+              done = true;
+            }
           }
         }
         if (it > cap && !done) { st |= ST_STEP_LIMIT; done = true; }
@@ -1050,10 +1052,10 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
     if (hi - bs > DTK_WINDOW && count_runes(s, bs, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
     if (MODE != MODE_START) {
       if (p > tp) {  // matrix.go:671-678
-        sink.template token<true>(bs, tp, p, ((F ^ 4u) & 7u) != 0);
+        sink.template token<IS_MATRIX>(bs, tp, p, ((F ^ 4u) & 7u) != 0);
         F = (F & ~3u) | 8u;
       }
-      sink.template tail<true>(bs, p, (F & 1u) != 0, (F & 2u) != 0, (F & 8u) != 0);  // matrix.go:683-691
+      sink.template tail<IS_MATRIX>(bs, p, (F & 1u) != 0, (F & 2u) != 0, (F & 8u) != 0);  // matrix.go:683-691
     }
   }
   st_out = st;
@@ -1068,7 +1070,7 @@ __device__ __forceinline__ void walk_any(const TRANS &tr, const uint16_t *__rest
                                          DtkLaneState &fin, uint32_t &st_out, uint32_t &steps_out,
                                          uint16_t *win_row) {
   if constexpr (TRANS::LEAN)
-    walk_fused<MODE, FIRST>(tr, sym_base, off, len, init, stop_pos, sink, epsilon, cap, fin, st_out, steps_out, win_row);
+    walk_fused<MODE, FIRST, IS_MATRIX>(tr, sym_base, off, len, init, stop_pos, sink, epsilon, cap, fin, st_out, steps_out, win_row);
   else
     walk_lane<TRANS, IS_MATRIX, MODE>(tr, sym_base, off, len, init, stop_pos, sink, epsilon, unknown, identity, cap,
                                       fin, st_out, steps_out, win_row);
@@ -2622,12 +2624,14 @@ static int with_trans(const DtkTableDev *tab, F &&f) {
   if (tab->kind == DTK_KIND_MATRIX) {
     if (tab->fused) {
       MatrixFusedTrans tr{(const uint32_t *)tab->tab, tab->stride, tab->n_eps, tab->start, tab->ident_guard};
+      // (da_dense: a double-array tokenizer laid out as a fused matrix -- the table's walk, datok.go's EOT rules)
+      auto call = [&](auto t) { if (tab->da_dense) f(t, std::false_type{}); else f(t, std::true_type{}); };
       if (tab->ident_guard == 0xFFFFFFFFu && !tab->plain_walk) {  // the lean loop applies
         MatrixLeanTrans lt;
         static_cast<MatrixFusedTrans &>(lt) = tr;
-        f(lt, std::true_type{});
+        call(lt);
       } else {
-        f(tr, std::true_type{});
+        call(tr);
       }
     } else if (tab->entry_bytes == 2) {
       MatrixTrans<uint16_t> tr{(const uint16_t *)tab->tab, tab->stride, tab->n_eps, tab->start};
@@ -2720,7 +2724,7 @@ extern "C" int dtk_launch_exact(const DtkTableDev *tab, const DtkExactArgs *args
     using TR = decltype(tr);
     if constexpr (TR::LEAN) {
       const MatrixFusedTrans base = tr;
-      hipLaunchKernelGGL((k_exact_doc<MatrixFusedTrans, true>), dim3(blocks), dim3(WAVE), 0, s, base, *args,
+      hipLaunchKernelGGL((k_exact_doc<MatrixFusedTrans, decltype(is_matrix)::value>), dim3(blocks), dim3(WAVE), 0, s, base, *args,
                          tab->epsilon, tab->unknown, tab->identity);
     } else {
       hipLaunchKernelGGL((k_exact_doc<TR, decltype(is_matrix)::value>), dim3(blocks), dim3(WAVE), 0, s, tr, *args,

@@ -105,6 +105,8 @@ typedef struct {
   uint32_t entry_bytes;  /* device table cell size (2 or 4 matrix, 8 double array) */
   uint64_t device_bytes; /* HBM held by the model */
   uint32_t unknown_used; /* 1 if any state has an arc on the unknown symbol */
+  uint32_t dense_states; /* double array only: its states, if its transitions were laid out as a matrix on the
+                          * device at load (entry_bytes is then 4); 0: the {base, check} pairs are walked */
 } dtk_model_info;
 int dtk_model_get_info(const dtk_model *m, dtk_model_info *out);
 

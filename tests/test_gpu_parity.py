@@ -639,6 +639,26 @@ def test_kernel_variants_forced_by_environment(env, tmp_path):
 
 
 @pytest.mark.gpu
+def test_double_array_dense_layout_and_pairs_path(gpu):
+    """A double-array tokenizer is walked through a dense (fused matrix) layout of its own transitions built at load
+    (dtk_host.cpp build_datok) -- every double-array test of this suite runs that way.  DATOK_NO_DENSE=1 keeps the
+    {base, check} pairs of the file on the device (DaTrans, two dependent loads per step): the same tests in a
+    process of their own, so that path stays exact too."""
+    import subprocess
+    for name in ("tokenizer_de.datok", "simpletok.datok"):
+        info = gpu(name).info
+        assert info["dense_states"] > 0 and info["entry_bytes"] == 4, info
+    assert gpu("tokenizer_de.matok").info["dense_states"] == 0
+    e = dict(os.environ); e["DATOK_NO_DENSE"] = "1"
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", "-k",
+                        "(datok or double_array or out_of_position or closure_int or edge_documents or config4 or "
+                        "speculative_chunks) and not pairs_path", os.path.join(ROOT, "tests")],
+                       capture_output=True, env=e, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout.decode()[-1500:], r.stderr.decode()[-500:])
+    assert b" passed" in r.stdout
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("model", ["tokenizer_de.matok", "tokenizer_de.datok"])
 @pytest.mark.parametrize("chunk", [64, 128, 256])
 def test_tokens_longer_than_warmup_and_chunk(gpu, oracle_models, model, chunk):
