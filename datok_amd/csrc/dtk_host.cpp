@@ -1280,7 +1280,8 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
     sp_first = sp;
     uint32_t *nb = (uint32_t *)(b->d_totals + 8);  // nb[0]: broken documents after the first pass, nb[r + 1]: after round r
     // DATOK_SPLIT_START=1: start records and chunk walk as two launches (the repair rounds' kernels)
-    static const bool split = getenv("DATOK_SPLIT_START") && atoi(getenv("DATOK_SPLIT_START")) != 0;
+    static const bool split_env = getenv("DATOK_SPLIT_START") && atoi(getenv("DATOK_SPLIT_START")) != 0;
+    const bool split = split_env || sp.lds_words == 0;  // (k_spec_both reports through the wave's LDS bitmaps)
     // Device-side repair: if the batch's last run had to repair (text with tags, say), two repair rounds are
     // enqueued right behind the first pass; their kernels return at once when the verification before them found
     // nothing broken, and the scan / compaction behind them only run once nothing is.  A miss then costs no host

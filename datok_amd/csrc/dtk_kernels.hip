@@ -496,8 +496,8 @@ struct EventSink {
   __device__ __forceinline__ void put_first(uint32_t kind, uint32_t pos) {
     if (DTK_KO & 8) return;
     const uint32_t G = gb + pos, m = 1u << (G & 31u);
-    if (lw) __hip_atomic_fetch_or(&lds[kind * lw + ((G >> 5) - w0)], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    else atomicOr(&g[kind * gw + (G >> 5)], m);  // (wave-uniform: no LDS bitmaps configured)
+    // (k_spec_both only runs with LDS bitmaps: without them dtk_batch_run launches start records and walk apart)
+    __hip_atomic_fetch_or(&lds[kind * lw + ((G >> 5) - w0)], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
   __device__ __forceinline__ void token_first(uint32_t tp, uint32_t p, bool sent_first) {
     c_tok++;
@@ -908,6 +908,13 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
     // right after a backtrack the bare epsilon symbol: width 0, that iteration consumes nothing (matrix.go:487-497)
     const uint32_t e_n = backtrack ? epsilon : en;
     const uint32_t x_n = DTK_TAB(t_n, e_n);
+    // nontoken && (comp || (advance && p == tp)), matrix.go:584-588.  (As lane masks combined in scalar registers,
+    //  and here, in the block of the comparisons: written with && / || or & / | further down the compiler builds
+    //  the predicate from 0/1 integers in vector registers, seven instructions instead of two.)
+    const unsigned long long m_comp = __builtin_amdgcn_ballot_w64((int32_t)x < 0),
+                             m_adv = m_comp | (__builtin_amdgcn_ballot_w64((int32_t)x > 0) & ~__builtin_amdgcn_ballot_w64(w == 0u));
+    const unsigned long long m_skip =
+        __builtin_amdgcn_ballot_w64((x & 0x8000u) != 0u) & (m_comp | (m_adv & __builtin_amdgcn_ballot_w64(p == tp)));
     uint32_t en_n;
     {
       const uint32_t pn_n = p_n + ((e_n >> DTK_SYM_W_SHIFT) & 7u);
@@ -921,7 +928,6 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
     }
     // ---- this iteration's bookkeeping, under the request
     hi = max(hi, pn);                                   // matrix.go:388-408
-    const bool nontoken = (x & 0x8000u) != 0;
     const bool epsE = comp || (plain && r);             // an epsilon arc is taken at p
     const bool flush = epsE && p > tp;                  // matrix.go:565-572
     const bool sentE = epsE && p <= tp;                 // matrix.go:573-576
@@ -943,9 +949,9 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
     const uint32_t bs_old = bs, p_old = p;
     F = flush ? 12u : (F | (sentE ? 1u : 0u));
     bs = flush ? p_old : bs;
-    const bool skip = nontoken && (comp || (advance && p_old == tp));  // matrix.go:584-588
+
     tp = (comp || flush) ? p_old : tp;
-    tp = skip ? pn : tp;
+    tp = __builtin_amdgcn_inverse_ballot_w64(m_skip) ? pn : tp;
     // the epsilon slot: dropped by a backtrack and by every epsilon step; a fused cell remembers the state it
     // read its rune in (the epsilon target, at p_old) if that state has an epsilon arc
     const bool he2 = comp && via <= n_eps;
