@@ -417,6 +417,7 @@ struct EventSink {
   uint32_t *g;         // the batch's bitmaps
   uint32_t gw;         // words per kind
   uint32_t gb;         // bit of position 0 of the document
+  uint32_t gbr;        // the same, counted from LDS word 0
   dtk_lds_u32 *lds;    // the wave's bitmaps in LDS (END, START, SEPS); lw == 0: none
   uint32_t lw;         // words per kind there
   uint32_t w0;         // global word of LDS word 0
@@ -434,7 +435,7 @@ struct EventSink {
   __device__ __forceinline__ void init(const DtkWalkArgs &A, uint64_t off, uint32_t d, uint32_t wlo, uint32_t whi,
                                        uint32_t *lds_bits = nullptr, uint32_t lds_words = 0, uint32_t word0 = 0) {
     g = A.bits; gw = A.bit_words; gb = (uint32_t)DTK_EV_BIT(off, d); tailw = A.doc_tail ? A.doc_tail + d : nullptr;
-    lds = (dtk_lds_u32 *)lds_bits; lw = lds_bits ? lds_words : 0u; w0 = word0;
+    lds = (dtk_lds_u32 *)lds_bits; lw = lds_bits ? lds_words : 0u; w0 = word0; gbr = gb - (word0 << 5);
     lo = wlo; hi = whi;
     last_s_p = last_eot_p = 0xFFFFFFFFu; st = 0; dropped = 0;
     c_tok = c_sent = c_text = 0;
@@ -495,9 +496,10 @@ struct EventSink {
   // test, no range test.  What a lane reports at or behind its stop position goes through the calls above.
   __device__ __forceinline__ void put_first(uint32_t kind, uint32_t pos) {
     if (DTK_KO & 8) return;
-    const uint32_t G = gb + pos, m = 1u << (G & 31u);
-    // (k_spec_both only runs with LDS bitmaps: without them dtk_batch_run launches start records and walk apart)
-    __hip_atomic_fetch_or(&lds[kind * lw + ((G >> 5) - w0)], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    // (k_spec_both only runs with LDS bitmaps: without them dtk_batch_run launches start records and walk apart;
+    //  gbr = the document's bit base relative to the wave's first LDS word)
+    const uint32_t G = gbr + pos;
+    __hip_atomic_fetch_or(&lds[kind * lw + (G >> 5)], 1u << (G & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
   __device__ __forceinline__ void token_first(uint32_t tp, uint32_t p, bool sent_first) {
     c_tok++;
@@ -824,7 +826,8 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
   uint32_t F = (init.flags & (LANE_F_SENT | LANE_F_TEXT)) | (init.p > 0 ? 4u : 0u);
   F |= (init.p > 0 && !(init.flags & LANE_F_TEXT)) ? 8u : 0u;
   static_assert(LANE_F_SENT == 1u && LANE_F_TEXT == 2u, "flag layout");
-  uint32_t st = 0, it = 0;
+  uint32_t st = 0;
+  uint32_t budget = cap;  // lookups left; the one that finds none left sets ST_STEP_LIMIT
   fin.p = 0xFFFFFFFFu; fin.t = 0; fin.aux = 0; fin.flags = 0;  // p stays "ran to EOF" unless the lane stops
   bool done = false;
   // the lane's window of the symbol stream: entry of position q at row[q - wb7], q - wb7 in [0, DTK_WIN)
@@ -844,7 +847,7 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
   if (p >= len) {                                                                                             \
     while (t <= n_eps && !done) {                                                                             \
       const uint32_t x_ = tab[__umul24(t, stride) + epsilon];                                                 \
-      it++;                                                                                                   \
+      const bool ov_ = __builtin_usub_overflow(budget, 1u, &budget);                                          \
       if ((int32_t)x_ <= 0) { st |= ST_BAD_MODEL; done = true; break; }                                       \
       if (p > tp) { /* matrix.go:565-572 */                                                                   \
         if (MODE != MODE_START) sink.template token<IS_MATRIX>(bs, tp, p, ((F ^ 4u) & 7u) != 0);                   \
@@ -860,7 +863,7 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
         F |= 1u;                                                                                              \
       }                                                                                                       \
       t = x_ & 0x7FFFu;                                                                                       \
-      if (it > cap) { st |= ST_STEP_LIMIT; done = true; }                                                     \
+      if (ov_) { st |= ST_STEP_LIMIT; done = true; }                                                          \
     }                                                                                                         \
     if (!done) {                                                                                              \
       if (eps_t != 0) { t = eps_t; p = eps_p; eps_t = 0; e = epsilon; } else done = true;                     \
@@ -888,7 +891,8 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
   unsigned long long pr_wait = 0, pr_t0 = clock64(), pr_n = 0;
 #endif
   while (!done) {
-    it++;
+    // (the lookup cap as a budget counted down: the borrow of the subtraction is the test -- one instruction, not two)
+    const bool over = __builtin_usub_overflow(budget, 1u, &budget);
     const uint32_t w = (e >> DTK_SYM_W_SHIFT) & 7u;     // bytes of the rune at p; 0: an epsilon iteration
     const uint32_t pn = p + w;
     // matrix.go:442-454.  (An epsilon iteration -- state and position of the slot it was popped from -- would put
@@ -966,7 +970,7 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
     const bool at_stop = flush && beyond;
     // (one chain of bit operations: `||` makes the compiler branch between the tests)
     if (hardfail | eot_now | (beyond & (FIRST ? epsE : flush)) | (flush & (win > DTK_WINDOW)) | (win > DTK_WINDOW_BYTES) |
-        (it > cap) | ((p >= len) & !backtrack)) {
+        over | ((p >= len) & !backtrack)) {
       if (FIRST && MODE != MODE_START && beyond && !(DTK_KO & 1)) {  // what the common path left to this block
         if (flush) sink.template token<IS_MATRIX>(bs_old, tp_old, p_old, ((F_old ^ 4u) & 7u) != 0);
         if (sentE) sink.template sentence<IS_MATRIX>(bs_old, p_old, (F_old & 8u) != 0);
@@ -1010,7 +1014,7 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
             }
           }
         }
-        if (it > cap && !done) { st |= ST_STEP_LIMIT; done = true; }
+        if (over && !done) { st |= ST_STEP_LIMIT; done = true; }
         // More bytes buffered than 1024 runes can have: the reference's window has overflowed for certain
         // (matrix.go:365,406).  The lane stops there -- a blank-free blob of megabytes would otherwise be walked to
         // its end by every lane whose chunk lies inside it.  (The tail below then closes the document at this
@@ -1065,7 +1069,7 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
     }
   }
   st_out = st;
-  steps_out = it;  // lookups
+  steps_out = cap - budget;  // lookups (modulo 2^32: the budget wraps when it runs out)
 }
 
 // the lean walk: fused cells and no arc on `unknown` (MatrixLeanTrans, picked by the launcher)
