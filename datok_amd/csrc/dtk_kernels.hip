@@ -1787,7 +1787,7 @@ __device__ __forceinline__ bool seg_range(const DtkCompactArgs &A, uint32_t s, u
 __device__ __forceinline__ uint32_t bits32(const uint32_t *__restrict__ b, uint32_t bit) {
   const uint32_t w = bit >> 5, sh = bit & 31u;
   const uint32_t lo = b[w], hi = b[w + 1];
-  return sh ? (lo >> sh) | (hi << (32u - sh)) : lo;
+  return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh);  // (one 64-bit shift: no test of sh between the loads and their use)
 }
 __device__ __forceinline__ uint32_t lowmask(uint32_t n) { return n >= 32u ? 0xFFFFFFFFu : (1u << n) - 1u; }
 
@@ -1813,11 +1813,20 @@ __device__ __forceinline__ void compact_unit(const DtkCompactArgs &A, uint32_t s
   __shared__ uint32_t qpos[FULL ? CQ_CAP : 1u], qrn[FULL ? CQ_CAP : 1u], qst[FULL ? CQ_CAP : 1u], qsr[FULL ? CQ_CAP : 1u];
   __shared__ uint8_t qfl[FULL ? CQ_CAP : 1u];
   const bool seg_mode = A.seg_doc != nullptr;
-  if (A.skip_if && *A.skip_if != 0u) return;  // documents are still to be repaired: the host runs this pass afterwards
   // one wave per segment, per document, or per document of the list of those that k_compact_small leaves to me
-  const uint32_t d = seg_mode ? A.seg_doc[blockIdx.x] : (big_docs ? big_docs[blockIdx.x] : blockIdx.x);
-  const uint64_t off = A.doc_off[d];
-  const uint32_t len = (uint32_t)(A.doc_off[d + 1] - off);
+  // (a scalar: what is indexed with it below then comes through the scalar cache, in one batch of requests)
+  const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane(
+      (int)(seg_mode ? A.seg_doc[blockIdx.x] : (big_docs ? big_docs[blockIdx.x] : blockIdx.x)));
+  // Everything the wave needs to know about its document, requested before any of it is looked at: the tests
+  // below used to stand between the loads, seven memory round trips in a row before the first tile.
+  const uint32_t skip_now = A.skip_if ? *A.skip_if : 0u;
+  const uint64_t off = A.doc_off[d], off_end = A.doc_off[d + 1];
+  const uint32_t st_d = A.status[d], tail_d = A.doc_tail[d];
+  const uint64_t tot0 = A.totals[0], tot1 = A.totals[1], tot2 = A.totals[2];
+  const uint64_t tok_base = A.tok_off[d], sent_base = A.sent_off[d], text_base = A.text_off[d];
+  const uint64_t tok_lim = A.tok_off[d + 1], sent_lim = A.sent_off[d + 1], text_lim = A.text_off[d + 1];
+  if (skip_now != 0u) return;  // documents are still to be repaired: the host runs this pass afterwards
+  const uint32_t len = (uint32_t)(off_end - off);
   if (len <= small_max && small_max != 0u) return;  // (segment mode: a small document's one segment)
   const uint32_t gb = (uint32_t)DTK_EV_BIT(off, d);
   const uint32_t *__restrict__ bE = A.bits + (size_t)EVB_END * A.bit_words;
@@ -1831,18 +1840,16 @@ __device__ __forceinline__ void compact_unit(const DtkCompactArgs &A, uint32_t s
   const uint32_t lane = lane_id();
   const unsigned long long lt = lanemask_lt();
   // a document whose calls are not in position order: its rows are written by the exact pass (k_exact_doc)
-  if (A.status[d] & ST_IRREGULAR) {
+  if (st_d & ST_IRREGULAR) {
     if (lane == 0) atomicOr(A.any_irregular, 1u);
     return;
   }
 
   // rows were sized by the walk's counts + scan; skip everything if the output arrays
   // are too small (the host grows them and re-launches this pass)
-  if (A.totals[0] > A.tok_cap || A.totals[1] > A.sent_cap || A.totals[2] > A.text_cap) return;
-  const uint64_t tok_base = A.tok_off[d], sent_base = A.sent_off[d], text_base = A.text_off[d];
-  const uint64_t tok_lim = A.tok_off[d + 1], sent_lim = A.sent_off[d + 1], text_lim = A.text_off[d + 1];
+  if (tot0 > A.tok_cap || tot1 > A.sent_cap || tot2 > A.text_cap) return;
   {
-    const bool has_eot = text_lim - text_base != 1ull || !(A.doc_tail[d] & DTK_TAIL_E);
+    const bool has_eot = text_lim - text_base != 1ull || !(tail_d & DTK_TAIL_E);
     if (has_eot != FULL) {
       if (!FULL && lane == 0) atomicOr(A.any_eot, 1u);
       return;
@@ -2067,11 +2074,20 @@ __device__ __forceinline__ void compact_unit(const DtkCompactArgs &A, uint32_t s
     // ---- the lane's words: positions q0 .. q0 + 31
     const uint32_t q0 = T0 + 32u * lane;
     uint32_t wE = 0, wS = 0, wP = 0, wT = 0, wU = 0, wR = 0;
+    {
+      // twelve loads in one go: a lane whose 32 positions lie behind the document reads the tile's first word
+      // instead and masks everything (a test around the loads makes them wait for each other)
+      const bool in = q0 < n_pos;
+      const uint32_t qc = in ? q0 : T0;
+      const uint32_t valid = in ? lowmask(n_pos - q0) : 0u;
+      const uint32_t validR = q0 < len ? lowmask(len - q0) : 0u;
+      const uint32_t qr = q0 < len ? q0 : (T0 < len ? T0 : 0u);
+      const uint32_t xE = bits32(bE, gb + qc), xS = bits32(bS, gb + qc), xP = bits32(bP, gb + qc);
+      const uint32_t xT = bits32(bT, gb + qc), xU = bits32(bU, gb + qc);
+      const uint32_t xR = bits32(A.rs_bits, (uint32_t)off + qr);  // rune starts: bit = input byte
+      wE = xE & valid; wS = xS & valid; wP = xP & valid; wT = xT & valid; wU = xU & valid; wR = xR & validR;
+    }
     if (q0 < n_pos) {
-      const uint32_t valid = lowmask(n_pos - q0);
-      wE = bits32(bE, gb + q0) & valid; wS = bits32(bS, gb + q0) & valid; wP = bits32(bP, gb + q0) & valid;
-      wT = bits32(bT, gb + q0) & valid; wU = bits32(bU, gb + q0) & valid;
-      if (q0 < len) wR = bits32(A.rs_bits, (uint32_t)off + q0) & lowmask(len - q0);  // rune starts: bit = input byte
       if (seg_mode) {  // closing kinds in (p0, p1], opening kinds in [p0, p1) or, at the end, [p0, p1]
         if (q0 == sr.p0) { wE &= ~1u; wT &= ~1u; wU &= ~1u; }
         if (!sr.last && sr.p1 >= q0 && sr.p1 - q0 < 32u) { wS &= ~(1u << (sr.p1 - q0)); wP &= ~(1u << (sr.p1 - q0)); }
@@ -2259,7 +2275,7 @@ __device__ __forceinline__ void compact_unit(const DtkCompactArgs &A, uint32_t s
   }
   if (sr.last) {
     // the final SentenceEnd / TextEnd of the document (matrix.go:683-691), behind everything: from the carries
-    const uint32_t tw = A.doc_tail[d];
+    const uint32_t tw = tail_d;
     const bool empty = cTE == (cHaveE ? cTokAtLastE : 0u);  // the text has no token (token_writer.go:108,135 panic)
     if ((tw & 3u) && empty) status |= ST_EMPTY_TEXT;
     if (tw & DTK_TAIL_S) {
