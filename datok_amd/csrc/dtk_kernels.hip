@@ -1767,6 +1767,7 @@ __global__ __launch_bounds__(256) void k_redo_clear(DtkWalkArgs A, DtkSpecArgs S
 // ------------------------------------------------------------------ compact
 
 #define CQ_CAP 512u  // ring capacity in queued positions (power of two; one light step adds at most 256)
+#define CT_CAP 512u  // rows of a fast tile staged in LDS (a tile of 2048 positions holds ~300-450 tokens; more go out directly)
 
 // Range of one segment of a long document: closing kinds in (p0, p1], opening kinds in
 // [p0, p1) -- or [p0, p1] for the document's last segment.  false: nothing to do.
@@ -1808,10 +1809,30 @@ __device__ __forceinline__ uint32_t lowmask(uint32_t n) { return n >= 32u ? 0xFF
 // what the walk counted: a document has an EOT call iff it has more than one TextEnd or its only TextEnd is not the
 // tail's.  The first kernel tells the host that the second is needed (any_eot); a batch object whose last run
 // needed it launches it right away (dtk_host.cpp).
+#ifdef DTK_PROBE
+// cycles per wave of k_compact_plain: prologue, tile loads + rune scan, counts + latch, token loop, sentence loop +
+// carries, tail; [6] waves, [7] tiles
+__device__ unsigned long long g_cphase[8];
+extern "C" int dtk_cphase_read(unsigned long long *out, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cphase), sizeof(g_cphase));
+  if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_cphase), z, sizeof(z)); }
+  return 0;
+}
+#define CPROBE(i) do { if (!FULL) { const unsigned long long n_ = clock64(); pr_c[i] += n_ - pr_last; pr_last = n_; } } while (0)
+#else
+#define CPROBE(i) do { } while (0)
+#endif
+
 template <bool FULL>
 __device__ __forceinline__ void compact_unit(const DtkCompactArgs &A, uint32_t small_max, const uint32_t *big_docs) {
   __shared__ uint32_t qpos[FULL ? CQ_CAP : 1u], qrn[FULL ? CQ_CAP : 1u], qst[FULL ? CQ_CAP : 1u], qsr[FULL ? CQ_CAP : 1u];
   __shared__ uint8_t qfl[FULL ? CQ_CAP : 1u];
+  __shared__ uint2 s_tok[CT_CAP];      // a fast tile's rows on their way out (see the token loop)
+  __shared__ uint16_t s_sb[CT_CAP];
+#ifdef DTK_PROBE
+  unsigned long long pr_c[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pr_last = clock64();
+#endif
   const bool seg_mode = A.seg_doc != nullptr;
   // one wave per segment, per document, or per document of the list of those that k_compact_small leaves to me
   // (a scalar: what is indexed with it below then comes through the scalar cache, in one batch of requests)
@@ -1905,6 +1926,7 @@ __device__ __forceinline__ void compact_unit(const DtkCompactArgs &A, uint32_t s
   }
 
   const uint32_t n_pos = sr.p1 + 1u;  // cursor positions p0..p1
+  CPROBE(0);
 
   // ---- heavy: the queued positions, 64 at a time (all of them if `drain`)
   auto heavy_rounds = [&](bool drain) {
@@ -2114,6 +2136,7 @@ __device__ __forceinline__ void compact_unit(const DtkCompactArgs &A, uint32_t s
                          : (is_matrix ? cLastER + ((nl_rule && cLastEByte == '\n') ? 1u : 0u)
                                       : cLastEndR + ((nl_rule && cLastEndByte == '\n') ? 1u : 0u));
       }
+      CPROBE(1);
       const uint32_t nTok = (uint32_t)__popc(wE), nP = (uint32_t)__popc(wP);
       uint32_t tot2;
       const uint32_t ex2 = wave_excl_scan(nTok | (nP << 16), tot2);
@@ -2144,6 +2167,7 @@ __device__ __forceinline__ void compact_unit(const DtkCompactArgs &A, uint32_t s
       const unsigned long long below = mTokLanes & lt;
       const int32_t rendBelow_t = __shfl(myLastRend, below ? highest(below) : 0);
       const int32_t rendBelowW = below ? rendBelow_t : cLastRend;
+      CPROBE(2);
       // tokens
       uint32_t me = wE, j = 0;
       while (me) {
@@ -2151,6 +2175,7 @@ __device__ __forceinline__ void compact_unit(const DtkCompactArgs &A, uint32_t s
         me &= me - 1u;
         const uint32_t P = q0 + b, R = rB + (uint32_t)__popc(wR & lowmask(b));
         uint32_t sp, sR;
+        bool far = false;
         const uint32_t m = wS & lowmask(b);
         if (m) {
           const uint32_t sb = 31u - (uint32_t)__clz((int)m);
@@ -2168,19 +2193,33 @@ __device__ __forceinline__ void compact_unit(const DtkCompactArgs &A, uint32_t s
           sp = w ? q + 31u - (uint32_t)__clz((int)w) : sr.p0;
           sR = R;
           for (uint32_t z = sp; z < P; z += 32u) sR -= (uint32_t)__popc(bits32(A.rs_bits, (uint32_t)off + z) & lowmask(P - z));
+          far = true;
         }
-        const uint64_t k = tok_base + cTE + tokB + j;
-        if (k < tok_lim) {
+        // The rows go through LDS (four 16-bit fields relative to the tile, one 8-byte write) and leave as runs of
+        // consecutive rows below: written from here, lane by lane, every 4-byte store of the wave lands in another
+        // cache line -- 64 address cycles per store instruction, which is what this kernel's time was made of.
+        const uint32_t li = tokB + j;  // row within the tile
+        const uint64_t k = tok_base + cTE + li;
+        const uint32_t sbef = pB + (uint32_t)__popc(wP & lowmask(b));
+        if (li < CT_CAP) {
+          const bool direct = far || k >= tok_lim;
+          s_tok[li] = direct ? make_uint2(0xFFFFu, 0u)
+                             : make_uint2((sp - T0 + 64u) | ((P - T0 + 64u) << 16), (sR - cR + 64u) | ((R - cR + 64u) << 16));
+          if (A.tok_sbefore) s_sb[li] = (uint16_t)sbef;
+        }
+        if (k >= tok_lim) status |= ST_INTERNAL;
+        else if (far || li >= CT_CAP) {
           A.tok_bstart[k] = sp; A.tok_bend[k] = P;
           A.tok_rstart[k] = (int32_t)(sR - base); A.tok_rend[k] = (int32_t)(R - base);
-          if (A.tok_sbefore) A.tok_sbefore[k] = cNSev + pB + (uint32_t)__popc(wP & lowmask(b));
-        } else status |= ST_INTERNAL;
+          if (A.tok_sbefore) A.tok_sbefore[k] = cNSev + sbef;
+        }
         if (sfm & (1u << b)) {  // token_writer.go:76-79
           const uint64_t si = sent_base + cNSent + sentB4 + (uint32_t)__popc(sfm & lowmask(b)) + (uint32_t)__popc(vP & lowmask(b));
           if (si < sent_lim) A.sent[si] = (int32_t)(sR - base); else status |= ST_INTERNAL;
         }
         j++;
       }
+      CPROBE(3);
       // SentenceEnds: the end offset of the last token at or below their position (token_writer.go:108)
       uint32_t mp = vP;
       while (mp) {
@@ -2191,6 +2230,22 @@ __device__ __forceinline__ void compact_unit(const DtkCompactArgs &A, uint32_t s
         if (e) v = (int32_t)(rB + (uint32_t)__popc(wR & lowmask(31u - (uint32_t)__clz((int)e))) - base);
         const uint64_t si = sent_base + cNSent + sentB4 + (uint32_t)__popc(sfm & lowmask(b + 1u)) + (uint32_t)__popc(vP & lowmask(b));
         if (si < sent_lim) A.sent[si] = v; else status |= ST_INTERNAL;
+      }
+      // the tile's rows: lane i writes rows i, i + 64, ... -- consecutive addresses across the wave
+      {
+        __syncthreads();
+        const uint32_t tn = (tot2 & 0xFFFFu) < CT_CAP ? (tot2 & 0xFFFFu) : CT_CAP;
+        const uint32_t pb = T0 - 64u, rb = cR - base - 64u;
+        for (uint32_t i = lane; i < tn; i += WAVE) {
+          const uint2 v = s_tok[i];
+          const uint64_t k = tok_base + cTE + i;
+          if ((v.x & 0xFFFFu) != 0xFFFFu) {
+            A.tok_bstart[k] = (v.x & 0xFFFFu) + pb; A.tok_bend[k] = (v.x >> 16) + pb;
+            A.tok_rstart[k] = (int32_t)((v.y & 0xFFFFu) + rb); A.tok_rend[k] = (int32_t)((v.y >> 16) + rb);
+            if (A.tok_sbefore) A.tok_sbefore[k] = cNSev + s_sb[i];
+          }
+        }
+        __syncthreads();
       }
       // carries
       if (mTokLanes) {
@@ -2269,6 +2324,10 @@ __device__ __forceinline__ void compact_unit(const DtkCompactArgs &A, uint32_t s
       heavy_rounds(true);  // nothing stays queued across a tile: the next one may take the fast path
       __syncthreads();
     }
+    CPROBE(4);
+#ifdef DTK_PROBE
+    pr_c[7]++;
+#endif
     // hand the last lane's words to the next tile's first lane
     pS_in = __shfl(wS, WAVE - 1); pR_in = __shfl(wR, WAVE - 1); pRb_in = __shfl(rB, WAVE - 1);
     cR += tileR;
@@ -2315,6 +2374,13 @@ __device__ __forceinline__ void compact_unit(const DtkCompactArgs &A, uint32_t s
     }
     if (sr.last && A.doc_ns) A.doc_ns[d] = cNSev;  // SentenceEnd calls of this document (for rendering)
   }
+#ifdef DTK_PROBE
+  CPROBE(5);
+  if (!FULL && lane == 0) {
+    for (int i = 0; i < 6; i++) atomicAdd(&g_cphase[i], pr_c[i]);
+    atomicAdd(&g_cphase[6], 1ull); atomicAdd(&g_cphase[7], pr_c[7]);
+  }
+#endif
 }
 
 // (69 VGPRs.  Forced down to 64 for eight waves per SIMD the compiler spills four of them: slower, 22.6 -> 25.1 us per

@@ -24,6 +24,7 @@ for k in range(n):
 out = (ctypes.c_ulonglong * 8)()
 lib.dtk_probe_read(out, 1)
 lib.dtk_phase_read((ctypes.c_ulonglong * 8)(), 1)
+lib.dtk_cphase_read((ctypes.c_ulonglong * 8)(), 1)
 t0 = time.perf_counter()
 R = 10
 for i in range(R):
@@ -43,4 +44,9 @@ lib.dtk_phase_read(ph, 0)
 w = max(ph[4], 1)
 print("k_spec_both cycles per wave: prologue + blank/tag search %.0f, warm-up walk %.0f, chunk walk %.0f, epilogue %.0f" % (
     ph[0] / w, ph[1] / w, ph[2] / w, ph[3] / w))
+cp = (ctypes.c_ulonglong * 8)()
+lib.dtk_cphase_read(cp, 0)
+w = max(cp[6], 1)
+print("k_compact_plain cycles per wave (%.1f tiles): prologue %.0f, tile loads + rune scan %.0f, counts + latch %.0f, token loop %.0f, "
+      "sentence loop + carries %.0f, tail %.0f" % ((cp[7] / w,) + tuple(cp[i] / w for i in range(6))))
 print("step %.1f us with %d in flight" % (dt / R / n * 1e6, n))
