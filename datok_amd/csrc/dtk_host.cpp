@@ -803,7 +803,7 @@ struct dtk_batch {
   uint32_t dev_rounds = 0;       // repair rounds enqueued ahead of time in the last run
   bool expect_repairs = false;   // the last run needed repairs: enqueue rounds ahead of time in the next one
   bool acc_primed = false;       // the accumulator block has been cleared whole once (k_symbolize clears it from then on)
-  uint64_t invalid_base = 0;     // the device's running count of invalid bytes before the last run
+  uint64_t epoch = 0;            // number of the run (k_symbolize marks runs that saw invalid UTF-8 with it)
   bool expect_eot = false;       // the last run had documents with EOT calls: launch their compaction kernel with the run
   bool ran_full = false;         // that kernel has run since the last dtk_batch_run
   uint64_t *h_totals = nullptr;  // pinned
@@ -819,7 +819,7 @@ struct dtk_batch {
   uint64_t *d_out_off = nullptr;
   uint8_t *d_out = nullptr;   uint64_t out_cap = 0;
   uint64_t out_total = 0;
-  uint64_t n_invalid = 0;     // invalid UTF-8 bytes of the last run (each prints as U+FFFD, 3 bytes)
+  uint64_t n_invalid = 0;     // nonzero: the last run saw invalid UTF-8 (each such byte prints as U+FFFD, 3 bytes)
   uint32_t render_flags = 0xFFFFFFFFu;  // flags of the rendering held in d_out (none)
   std::vector<uint8_t> h_out;
   std::vector<uint64_t> h_out_off;
@@ -1250,14 +1250,13 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
     b->bit_words = (uint32_t)(((b->total + nd) / 32 + 8) & ~(uint64_t)3);  // 16-byte multiples per kind
     // (the event bitmaps are cleared by k_symbolize's blocks, unless it does not run)
     const bool fold = b->total > 0 && !(skip & 1);
-    // ... and the accumulator block too, once it has been cleared whole (totals[6], the invalid-byte count, is left
-    // out there: a running count the host takes differences of) and as long as every run's totals were read
-    fold_acc = fold && b->acc_primed && (!b->ran || b->totals_valid) && acc_used / 16 < 0xFFFFFFFFull &&
+    // ... and the accumulator block too, once it has been cleared whole (totals[6], which k_symbolize's own blocks
+    // write, is left out there: it holds the number of the last run that saw invalid UTF-8)
+    fold_acc = fold && b->acc_primed && acc_used / 16 < 0xFFFFFFFFull &&
                !getenv("DATOK_CLEAR_KERNEL");
     if (!fold_acc) {
       if (dtk_launch_clear2(b->d_acc, acc_used, b->d_bits, (fold || (skip & 4)) ? 0 : (size_t)EVB_KINDS * b->bit_words * 4, s))
         return hip_fail(hipGetLastError(), "clear");
-      b->invalid_base = 0;
       b->acc_primed = true;
     }
     acc_bytes = acc_used;
@@ -1265,7 +1264,7 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
   STAGE(1);
   if (!(skip & 1) && dtk_launch_symbolize(b->d_text, b->d_off, b->n_docs, b->total, &m->sig, b->d_sym,
                            b->d_text == b->d_text_own, b->d_blk_doc, (unsigned long long *)(b->d_totals + 6), b->d_rsbits,
-                           b->d_bits, b->bit_words, fold_acc ? b->d_acc : nullptr, acc_bytes, s))
+                           b->d_bits, b->bit_words, fold_acc ? b->d_acc : nullptr, acc_bytes, ++b->epoch, s))
     return hip_fail(hipGetLastError(), "symbolize");
   STAGE(2);
   DtkWalkArgs w = walk_args(b);
@@ -1463,8 +1462,7 @@ static int finish(dtk_batch *b) {
     b->expect_repairs = b->repair_rounds != 0;
   }
   const uint64_t nt = b->h_totals[0], ns = b->h_totals[1], nx = b->h_totals[2];
-  b->n_invalid = b->h_totals[6] - b->invalid_base;  // (a running count: k_symbolize)
-  b->invalid_base = b->h_totals[6];
+  b->n_invalid = b->h_totals[6] == b->epoch ? 1u : 0u;  // (the number of the last run that saw one: k_symbolize)
   if (nt > b->tok_cap || ns > b->sent_cap || nx > b->text_cap) {
     int rc = alloc_outputs(b, nt + nt / 8 + 16, ns + ns / 8 + 16, nx + nx / 8 + 16);
     if (rc != DTK_OK) return rc;

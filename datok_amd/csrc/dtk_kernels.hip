@@ -93,6 +93,7 @@ __device__ __forceinline__ uint32_t doc_of(const uint64_t *__restrict__ doc_off,
 #define SYM_SIG_LDS 64u  // runes >= 256 of the sigma kept in LDS (40 in the shipped models)
 #define SYM_HALF 1024u  // bytes per wave (its queue of bytes >= 0x80: 2 B of LDS per byte)
 #define SYM_THREADS (WAVE * (SYM_BLOCK_BYTES / SYM_HALF))  // 256: four waves per 4 KiB block
+#define SYM_DOFF 256u  // document offsets of a block kept in LDS (documents of 16 bytes on average and longer)
 
 template <bool ALIGNED4>
 __global__ __launch_bounds__(SYM_THREADS) void k_symbolize(const uint8_t *__restrict__ text,
@@ -103,11 +104,11 @@ __global__ __launch_bounds__(SYM_THREADS) void k_symbolize(const uint8_t *__rest
                                                     unsigned long long *__restrict__ n_invalid,
                                                     uint32_t *__restrict__ rs_bits,
                                                     uint32_t *__restrict__ ev_bits, uint32_t bit_words,
-                                                    uint4 *__restrict__ acc, uint32_t acc16) {
+                                                    uint4 *__restrict__ acc, uint32_t acc16,
+                                                    unsigned long long epoch) {
   // The run's accumulator block (totals, per-document counts, status and check words; dtk_batch_run) starts from
   // zero: the first blocks clear it here instead of a launch of its own in front (7 us of a batch's 230).  All but
-  // totals[6], the count of invalid bytes, which blocks of this very launch add to: it only ever grows and the host
-  // takes differences.
+  // totals[6], which blocks of this very launch write: the number of the last run that saw an invalid byte.
   if (acc) {
     const uint4 z = make_uint4(0u, 0u, 0u, 0u);
     for (uint32_t i = blockIdx.x * SYM_THREADS + threadIdx.x; i < acc16; i += gridDim.x * SYM_THREADS) {
@@ -122,6 +123,7 @@ __global__ __launch_bounds__(SYM_THREADS) void k_symbolize(const uint8_t *__rest
   __shared__ uint16_t s_syms[SYM_SIG_LDS];
   __shared__ uint32_t s_txt[SYM_BLOCK_BYTES / 4 + 4];  // the block's bytes, one dword of halo either side
   __shared__ uint16_t s_qs[SYM_BLOCK_BYTES / SYM_HALF][SYM_HALF];  // per wave: positions (offset in the block) of the bytes >= 0x80 of its quarter
+  __shared__ uint64_t s_doff[SYM_DOFF];  // the offsets of the documents of this block (if they are that few)
   const uint32_t tid = threadIdx.x, lane = tid & (WAVE - 1u), half = tid >> 6;  // one wave per quarter (1 KiB) of the block
   uint16_t *s_q = s_qs[half];
   const bool sig_lds = sig.n_runes <= SYM_SIG_LDS;
@@ -135,6 +137,14 @@ __global__ __launch_bounds__(SYM_THREADS) void k_symbolize(const uint8_t *__rest
   }
   const uint64_t block_start = (uint64_t)blockIdx.x * SYM_BLOCK_BYTES;
   const uint32_t n_here = (uint32_t)min((uint64_t)SYM_BLOCK_BYTES, total - block_start);
+  // documents that can own bytes of this block: host-computed (document of each block's
+  // first byte), so no lane walks the offset table from scratch
+  const uint32_t d_lo = blk_doc[blockIdx.x];
+  const uint32_t d_hi = min(blk_doc[blockIdx.x + 1], n_docs - 1);
+  // their offsets, doc_off[d_lo .. d_hi + 1], in LDS: a block of tiny documents otherwise searches the table in memory
+  // once per byte >= 0x80 (six dependent loads each; 64-byte documents: 203 us of symbolising per 32 MiB)
+  const uint32_t n_off = d_hi - d_lo + 2u;
+  if (n_off <= SYM_DOFF && tid < n_off) s_doff[tid] = doc_off[d_lo + tid];
   {
     // all loads of the block are issued before anything waits for one of them
     auto load4 = [&](uint64_t g) -> uint32_t {  // bytes g..g+3, zero outside [0, total)
@@ -158,10 +168,6 @@ __global__ __launch_bounds__(SYM_THREADS) void k_symbolize(const uint8_t *__rest
   __syncthreads();
   const uint8_t *__restrict__ sb = reinterpret_cast<const uint8_t *>(s_txt) + 4;  // sb[i] = text[block_start + i]
 
-  // documents that can own bytes of this block: host-computed (document of each block's
-  // first byte), so no lane walks the offset table from scratch
-  const uint32_t d_lo = blk_doc[blockIdx.x];
-  const uint32_t d_hi = min(blk_doc[blockIdx.x + 1], n_docs - 1);
   const uint64_t lo_start = doc_off[d_lo], lo_end = doc_off[d_lo + 1];  // the block's first document
   if (ev_bits) {
     // The walk's event bitmaps start from zero: every block clears the words of the cursor positions of its bytes
@@ -236,13 +242,23 @@ __global__ __launch_bounds__(SYM_THREADS) void k_symbolize(const uint8_t *__rest
 
     // ---- heavy: one queued position per lane
     for (uint32_t q0 = 0; q0 < nq; q0 += WAVE) {
+      bool bad = false;
       if (q0 + lane < nq) {
         const uint32_t pos = s_q[q0 + lane];
         const uint64_t g = block_start + pos;
         uint64_t dstart = lo_start, dend = lo_end;
         if (g >= lo_end) {  // a later document of this block
-          const uint32_t d = doc_of(doc_off, d_lo, d_hi + 1, g);
-          dstart = doc_off[d]; dend = doc_off[d + 1];
+          if (n_off <= SYM_DOFF) {
+            uint32_t lo = 0, hi = n_off - 1u;  // largest i with s_doff[i] <= g  (s_doff[0] <= g < s_doff[n_off - 1])
+            while (hi - lo > 1u) {
+              const uint32_t mid = lo + ((hi - lo) >> 1);
+              if (s_doff[mid] <= g) lo = mid; else hi = mid;
+            }
+            dstart = s_doff[lo]; dend = s_doff[lo + 1u];
+          } else {
+            const uint32_t d = doc_of(doc_off, d_lo, d_hi + 1, g);
+            dstart = doc_off[d]; dend = doc_off[d + 1];
+          }
         }
         const uint64_t l64 = dend - g, b64 = g - dstart;
         const uint32_t avail = l64 > 8 ? 8u : (uint32_t)l64, back = b64 > 3 ? 3u : (uint32_t)b64;
@@ -294,8 +310,15 @@ __global__ __launch_bounds__(SYM_THREADS) void k_symbolize(const uint8_t *__rest
         sym[g] = (uint16_t)(a_cls | (start ? wd << DTK_SYM_W_SHIFT : 0u));
         if (start) atomicOr(&s_rs[pos >> 5], 1u << (pos & 31u));
         // a byte that decodes to U+FFFD with width 1 prints as three bytes (the renderer's slow path)
-        if (start && wd == 1u) atomicAdd(n_invalid, 1ull);
+        bad = start && wd == 1u;
       }
+      // The host only asks whether the run saw such a byte (the renderer's slow path): the word holds the number of
+      // the last run that did, and a wave looks before it writes.  (It used to be a count: documents cut through
+      // their runes -- 64-byte pieces of running text -- made 30 000 adds to this one address queue up, 140 us of
+      // a 32 MiB batch.)
+      if (__ballot(bad) != 0ull && lane == 0 &&
+          __hip_atomic_load(n_invalid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch)
+        atomicMax(n_invalid, epoch);
     }
   }
   // the block's rune-start bitmap (bit g of the array = input byte g): the compaction counts
@@ -2697,17 +2720,20 @@ extern "C" int dtk_launch_clear2(void *a, uint64_t a_bytes, void *b, uint64_t b_
 extern "C" int dtk_launch_symbolize(const uint8_t *text, const uint64_t *doc_off, uint32_t n_docs,
                                     uint64_t total, const DtkSigmaDev *sig, uint16_t *sym, int padded,
                                     const uint32_t *blk_doc, unsigned long long *n_invalid, uint32_t *rs_bits,
-                                    uint32_t *ev_bits, uint32_t bit_words, void *acc, uint64_t acc_bytes, void *stream) {
+                                    uint32_t *ev_bits, uint32_t bit_words, void *acc, uint64_t acc_bytes,
+                                    uint64_t epoch, void *stream) {
   if (total == 0 || n_docs == 0) return 0;
   const uint32_t blocks = (uint32_t)((total + SYM_BLOCK_BYTES - 1) / SYM_BLOCK_BYTES);
   // ALIGNED4 may read up to 3 bytes past `total`: true for the batch's own (padded) buffer;
   // a caller-owned device buffer only qualifies when its size is a multiple of 4
   if ((((uintptr_t)text) & 3u) == 0 && (padded || (total & 3u) == 0))
     hipLaunchKernelGGL(k_symbolize<true>, dim3(blocks), dim3(SYM_THREADS), 0, (hipStream_t)stream, text, doc_off, n_docs,
-                       total, *sig, sym, blk_doc, n_invalid, rs_bits, ev_bits, bit_words, (uint4 *)acc, (uint32_t)(acc_bytes / 16));
+                       total, *sig, sym, blk_doc, n_invalid, rs_bits, ev_bits, bit_words, (uint4 *)acc, (uint32_t)(acc_bytes / 16),
+                       (unsigned long long)epoch);
   else
     hipLaunchKernelGGL(k_symbolize<false>, dim3(blocks), dim3(SYM_THREADS), 0, (hipStream_t)stream, text, doc_off, n_docs,
-                       total, *sig, sym, blk_doc, n_invalid, rs_bits, ev_bits, bit_words, (uint4 *)acc, (uint32_t)(acc_bytes / 16));
+                       total, *sig, sym, blk_doc, n_invalid, rs_bits, ev_bits, bit_words, (uint4 *)acc, (uint32_t)(acc_bytes / 16),
+                       (unsigned long long)epoch);
   return (int)hipGetLastError();
 }
 
