@@ -899,7 +899,7 @@ extern "C" int dtk_batch_create(uint64_t max_bytes, uint32_t max_docs, dtk_batch
   // per array: total + 4 * n_docs + 4 slots, rounded up to 256 by dtk_batch_run
   // one bit per cursor position and kind: total + n_docs positions, rounded up to 16 bytes per kind, two words of slack
   B_TRY(hipMalloc((void **)&b->d_bits, (EVB_KINDS * ((max_bytes + max_docs) / 32 + 8) + 8) * 4));
-  b->acc_bytes = 128 + 3 * ((uint64_t)max_docs + 1) * 8 + 4 * (uint64_t)max_docs * 4 + 64;
+  b->acc_bytes = DTK_TOTALS_BYTES + 3 * ((uint64_t)max_docs + 1) * 8 + 4 * (uint64_t)max_docs * 4 + 64;
   B_TRY(hipMalloc((void **)&b->d_acc, b->acc_bytes));
   B_TRY(hipMalloc((void **)&b->d_redo, (uint64_t)max_docs * 4));
   B_TRY(hipMalloc((void **)&b->d_blk_doc, (max_bytes / DTK_SYM_BLOCK_BYTES + 3) * 4));
@@ -913,7 +913,8 @@ extern "C" int dtk_batch_create(uint64_t max_bytes, uint32_t max_docs, dtk_batch
   B_TRY(hipMalloc((void **)&b->d_scan_ws, ((uint64_t)max_docs / 2048 + 2) * 4 * 8));
   B_TRY(hipMalloc((void **)&b->d_out_off, ((uint64_t)max_docs + 1) * 8));
 
-  B_TRY(hipHostMalloc((void **)&b->h_totals, 16 * 8, hipHostMallocDefault));  // [0..9] device totals, [10] render size
+  // [0..15] device totals ([10] doubles as the render size), [16..] the striped lookup counters
+  B_TRY(hipHostMalloc((void **)&b->h_totals, DTK_TOTALS_BYTES, hipHostMallocDefault));
   B_TRY(hipHostMalloc((void **)&b->h_off_pin, ((uint64_t)max_docs + 1) * 8, hipHostMallocDefault));
 #undef B_TRY
   // typical German: 0.18 tokens and 0.06 sentence ints per byte; grown on demand
@@ -1135,7 +1136,7 @@ static DtkWalkArgs walk_args(dtk_batch *b) {
   w.sym = b->d_sym; w.doc_off = b->d_off; w.n_docs = b->n_docs;
   w.bits = b->d_bits; w.bit_words = b->bit_words; w.doc_tail = b->d_doc_tail; w.status = b->d_status;
   w.tok_cnt = b->d_tok_cnt; w.sent_cnt = b->d_sent_cnt; w.text_cnt = b->d_text_cnt;
-  w.steps = (unsigned long long *)(b->d_totals + 4);
+  w.steps = (unsigned long long *)(b->d_totals + 16);
   w.step_factor = 2048;  // look-ahead is bounded by the 1024-rune window (matrix.go:365)
   return w;
 }
@@ -1238,7 +1239,7 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
     // check words -- cleared together with the two event arrays by one launch
     const size_t nd = b->n_docs;
     uint8_t *q = b->d_acc;
-    b->d_totals = (uint64_t *)q; q += 128;
+    b->d_totals = (uint64_t *)q; q += DTK_TOTALS_BYTES;  // (the striped lookup counters right behind the totals)
     b->d_tok_cnt = (uint64_t *)q; q += (nd + 1) * 8;
     b->d_sent_cnt = (uint64_t *)q; q += (nd + 1) * 8;
     b->d_text_cnt = (uint64_t *)q; q += (nd + 1) * 8;
@@ -1326,7 +1327,7 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
   if (rc != DTK_OK) return rc;
   STAGE(9);
 #undef STAGE
-  HIP_TRY(hipMemcpyAsync(b->h_totals, b->d_totals, 10 * 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(b->h_totals, b->d_totals, DTK_TOTALS_BYTES, hipMemcpyDeviceToHost, s));
   b->ran = true;
   b->totals_valid = false;
   b->render_flags = 0xFFFFFFFFu;
@@ -1455,8 +1456,7 @@ static int finish(dtk_batch *b) {
       b->last_args.skip_if = nullptr;
       int rc = launch_compact2(b, 3);
       if (rc != DTK_OK) return rc;
-      HIP_TRY(hipMemcpyAsync(b->h_totals, b->d_totals, 5 * 8, hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipMemcpyAsync(b->h_totals + 7, b->d_totals + 7, 8, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipMemcpyAsync(b->h_totals, b->d_totals, DTK_TOTALS_BYTES, hipMemcpyDeviceToHost, s));
       HIP_TRY(hipStreamSynchronize(s));
     }
     b->expect_repairs = b->repair_rounds != 0;
@@ -1494,7 +1494,8 @@ static int finish(dtk_batch *b) {
   b->totals.n_sent = ns;
   b->totals.n_texts = nx;
   b->totals.n_flagged = b->h_totals[3];
-  b->totals.walk_steps = b->h_totals[4];
+  b->totals.walk_steps = 0;
+  for (uint32_t i = 0; i < DTK_STEP_STRIPES; i++) b->totals.walk_steps += b->h_totals[16 + 16 * i];
   b->totals.n_lanes = b->chunk ? b->n_lanes : b->n_docs;
   b->totals.chunk_bytes = b->chunk;
   b->totals.repair_rounds = b->repair_rounds;

@@ -73,6 +73,11 @@ struct DtkSigmaDev {
 enum { DTK_KIND_MATRIX = 0, DTK_KIND_DA = 1 };
 
 // Device table handed to the walk kernels.
+// The walk's lookup count (a statistic) is added up in 32 counters a cache line apart, picked by block id: one
+// counter took 2048 adds to one address from the waves of a batch as they finished, 5 us at the end of the walk.
+#define DTK_STEP_STRIPES 32u
+#define DTK_TOTALS_BYTES (128u + DTK_STEP_STRIPES * 128u)  // a batch's totals block + the counters behind it
+
 struct DtkTableDev {
   int kind;
   // matrix: state-major rows, cell (t, a) at tab[t*stride + a]; column 0 is all

@@ -1118,7 +1118,7 @@ __device__ __forceinline__ void add_steps(unsigned long long *counter, uint32_t 
   unsigned long long tot = mine;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) tot += __shfl_down(tot, o);
-  if (lane_id() == 0 && tot) atomicAdd(counter, tot);
+  if (lane_id() == 0 && tot) atomicAdd(counter + (blockIdx.x & (DTK_STEP_STRIPES - 1u)) * 16u, tot);  // see DTK_STEP_STRIPES
 }
 
 // ---- the exact pass: one lane per irregular document ----
@@ -1895,7 +1895,10 @@ __device__ __forceinline__ void compact_unit(const DtkCompactArgs &A, uint32_t s
   {
     const bool has_eot = text_lim - text_base != 1ull || !(tail_d & DTK_TAIL_E);
     if (has_eot != FULL) {
-      if (!FULL && lane == 0) atomicOr(A.any_eot, 1u);
+      // (looked at before it is written: a batch in which every document has an EOT would otherwise queue one
+      //  atomic per document at this address)
+      if (!FULL && lane == 0 && __hip_atomic_load(A.any_eot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+        atomicOr(A.any_eot, 1u);
       return;
     }
   }
