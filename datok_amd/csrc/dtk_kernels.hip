@@ -1591,7 +1591,8 @@ __global__ __launch_bounds__(WAVE) void k_spec_walk(TRANS tr, DtkWalkArgs A, Dtk
 // must have arrived exactly there) or it is the chain's last lane (then it must have reached EOF, and no later lane
 // may have a record: the lane in front of such a record, which has none itself, finds the chain's last lane by
 // walking back).  The first lane that fails is the same one in both formulations.
-__global__ __launch_bounds__(256) void k_spec_verify(DtkWalkArgs A, DtkSpecArgs S, uint32_t cmp_mask, uint32_t local_link) {
+#define VERIFY_TB 1024u
+__global__ __launch_bounds__(VERIFY_TB) void k_spec_verify(DtkWalkArgs A, DtkSpecArgs S, uint32_t cmp_mask, uint32_t local_link) {
   if (S.go && *S.go == 0u) return;
   const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
   bool live = L < S.n_lanes;  // every lane stays for the wave reduction below
@@ -1662,7 +1663,29 @@ __global__ __launch_bounds__(256) void k_spec_verify(DtkWalkArgs A, DtkSpecArgs 
   }
   const uint32_t dprev = __shfl_up(d, 1);
   const bool head = live && (lane_id() == 0 || dprev != d);
-  if (head) {
+  // A block whose 16 waves all lie inside one document adds up once more: the waves of a long document otherwise
+  // queue their atomics at the same three addresses (one 64 MiB document: 4096 waves, 106 us of verification).
+  __shared__ uint32_t s_d[VERIFY_TB / WAVE], s_v[VERIFY_TB / WAVE][4];
+  const uint32_t wid = threadIdx.x >> 6;
+  const bool whole = __ballot(head) == 1ull;  // one run of lanes, starting at lane 0
+  if (lane_id() == 0) {
+    s_d[wid] = whole ? d : 0xFFFFFFFFu;
+    s_v[wid][0] = tok; s_v[wid][1] = sent; s_v[wid][2] = text; s_v[wid][3] = st;
+  }
+  __syncthreads();
+  bool merged = s_d[0] != 0xFFFFFFFFu;
+#pragma unroll
+  for (uint32_t w = 1; w < VERIFY_TB / WAVE; w++) merged = merged && s_d[w] == s_d[0];
+  if (merged) {
+    if (threadIdx.x == 0) {
+      uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+      for (uint32_t w = 0; w < VERIFY_TB / WAVE; w++) { a0 += s_v[w][0]; a1 += s_v[w][1]; a2 += s_v[w][2]; a3 |= s_v[w][3]; }
+      if (a0) atomicAdd((unsigned long long *)&A.tok_cnt[d], (unsigned long long)a0);
+      if (a1) atomicAdd((unsigned long long *)&A.sent_cnt[d], (unsigned long long)a1);
+      if (a2) atomicAdd((unsigned long long *)&A.text_cnt[d], (unsigned long long)a2);
+      if (a3) atomicOr(&A.status[d], a3);
+    }
+  } else if (head) {
     if (tok) atomicAdd((unsigned long long *)&A.tok_cnt[d], (unsigned long long)tok);
     if (sent) atomicAdd((unsigned long long *)&A.sent_cnt[d], (unsigned long long)sent);
     if (text) atomicAdd((unsigned long long *)&A.text_cnt[d], (unsigned long long)text);
@@ -2814,10 +2837,10 @@ extern "C" int dtk_launch_spec(const DtkTableDev *tab, const DtkWalkArgs *args, 
                            tab->identity);
       });
     case 3:
-      hipLaunchKernelGGL(k_spec_verify, dim3(lane_blocks256), dim3(256), 0, s, *args, *spec, cmp_mask, 0u);
+      hipLaunchKernelGGL(k_spec_verify, dim3((spec->n_lanes + VERIFY_TB - 1u) / VERIFY_TB), dim3(VERIFY_TB), 0, s, *args, *spec, cmp_mask, 0u);
       return (int)hipGetLastError();
     case 7:  // first pass behind k_spec_both: link + verify in one
-      hipLaunchKernelGGL(k_spec_verify, dim3(lane_blocks256), dim3(256), 0, s, *args, *spec, cmp_mask, 1u);
+      hipLaunchKernelGGL(k_spec_verify, dim3((spec->n_lanes + VERIFY_TB - 1u) / VERIFY_TB), dim3(VERIFY_TB), 0, s, *args, *spec, cmp_mask, 1u);
       return (int)hipGetLastError();
     case 4:
       hipLaunchKernelGGL(k_spec_fix, dim3(doc_blocks), dim3(256), 0, s, *args, *spec, redo_out, n_bad);

@@ -1,0 +1,14 @@
+#!/bin/bash
+# end-of-round measurements: profiles (bench line, rocprofv3 stats, traffic), SQ / TCP / L2 counters of the
+# kernels with one batch alone, the other configurations and corpora
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r02
+bash scripts/round_profiles.sh r02 > gpurun_out/r02/round_profiles.log 2>&1 || { tail -5 gpurun_out/r02/round_profiles.log; exit 1; }
+bash scripts/pmc_groups.sh "k_spec_both|k_symbolize|k_compact_plain" --streams 1 > gpurun_out/r02/pmc_sq.txt 2>&1
+bash scripts/pmc_tcp.sh > gpurun_out/r02/pmc_tcp.txt 2>&1
+timeout -k 10 300 python scripts/configs.py > gpurun_out/r02/configs.txt 2>&1
+timeout -k 10 300 python scripts/robust.py > gpurun_out/r02/robust.txt 2>&1
+timeout -k 10 200 python scripts/tiny_docs.py > gpurun_out/r02/tiny.txt 2>&1
+timeout -k 10 200 python scripts/big_stages.py 32 > gpurun_out/r02/big_stages.txt 2>&1
+timeout -k 10 200 python scripts/stages3.py 65536 >> gpurun_out/r02/big_stages.txt 2>&1
+tail -3 gpurun_out/r02/configs.txt gpurun_out/r02/robust.txt gpurun_out/r02/tiny.txt gpurun_out/r02/big_stages.txt
