@@ -623,13 +623,17 @@ print("VARIANT OK")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{"DATOK_EV_LISTS": "1"}, {"DATOK_EV_LISTS": "0"}, {"DATOK_SPLIT_START": "1"},
-                                 {"DATOK_SPLIT_START": "1", "DATOK_EV_LISTS": "1"}],
-                         ids=["event-lists", "plain-stores", "split-start", "split-start+lists"])
+@pytest.mark.parametrize("env", [{"DATOK_LDS_BITS": "0"}, {"DATOK_SPLIT_START": "1"},
+                                 {"DATOK_SPLIT_START": "1", "DATOK_LDS_BITS": "0"}, {"DATOK_CLEAR_KERNEL": "1"},
+                                 {"DATOK_COMPACT_FULL": "1", "DATOK_DEV_ROUNDS": "2"}],
+                         ids=["no-lds-bitmaps", "split-start", "split-start+no-lds-bitmaps", "clear-kernel",
+                              "both-compactions+device-rounds"])
 def test_kernel_variants_forced_by_environment(env, tmp_path):
-    """The library picks the walk's kernels by batch size (event lists from 48 MiB on) and runs the first pass
-    as one launch; the other paths (small batches through lists, start records and walk as two launches, which is
-    also what repair rounds use) must give the same offsets.  The switches are read once per process."""
+    """The library runs the first pass as one launch that reports through the waves' LDS bitmaps, clears its
+    accumulators in k_symbolize and launches what a batch's last run needed; the other paths (event bits straight to
+    memory, start records and walk as two launches -- which is also what repair rounds use --, a clear kernel, both
+    compaction kernels and device-side repair rounds with every run) must give the same offsets.  The switches are
+    read once per process."""
     import subprocess
     script = tmp_path / "variant.py"
     script.write_text(_VARIANT_SCRIPT)
