@@ -2452,14 +2452,19 @@ __global__ __launch_bounds__(256) void k_compact_small(DtkCompactArgs A, uint32_
   if (A.skip_if && *A.skip_if != 0u) return;
   const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
   if (d >= A.n_docs) return;
-  const uint64_t off = A.doc_off[d];
-  const uint32_t len = (uint32_t)(A.doc_off[d + 1] - off);
-  if (len > small_max) return;
-  if (A.status[d] & ST_IRREGULAR) { atomicOr(A.any_irregular, 1u); return; }
-  if (A.totals[0] > A.tok_cap || A.totals[1] > A.sent_cap || A.totals[2] > A.text_cap) return;
+  // (all of the document's facts requested before any is tested: the tests used to stand between the loads)
+  const uint64_t off = A.doc_off[d], off_end = A.doc_off[d + 1];
+  const uint32_t st_d = A.status[d];
+  const uint64_t tot0 = A.totals[0], tot1 = A.totals[1], tot2 = A.totals[2];
   const uint64_t tok_base = A.tok_off[d], sent_base = A.sent_off[d], text_base = A.text_off[d];
-  const uint32_t tok_n = (uint32_t)(A.tok_off[d + 1] - tok_base), sent_n = (uint32_t)(A.sent_off[d + 1] - sent_base),
-                 text_n = (uint32_t)(A.text_off[d + 1] - text_base);
+  const uint64_t tok_lim = A.tok_off[d + 1], sent_lim = A.sent_off[d + 1], text_lim = A.text_off[d + 1];
+  const uint32_t tw = A.doc_tail[d];         // matrix.go:683-691
+  const uint32_t len = (uint32_t)(off_end - off);
+  if (len > small_max) return;
+  if (st_d & ST_IRREGULAR) { atomicOr(A.any_irregular, 1u); return; }
+  if (tot0 > A.tok_cap || tot1 > A.sent_cap || tot2 > A.text_cap) return;
+  const uint32_t tok_n = (uint32_t)(tok_lim - tok_base), sent_n = (uint32_t)(sent_lim - sent_base),
+                 text_n = (uint32_t)(text_lim - text_base);
   const uint32_t gb = (uint32_t)DTK_EV_BIT(off, d);
   const uint32_t *__restrict__ bE = A.bits + (size_t)EVB_END * A.bit_words;
   const uint32_t *__restrict__ bS = A.bits + (size_t)EVB_START * A.bit_words;
@@ -2490,11 +2495,19 @@ __global__ __launch_bounds__(256) void k_compact_small(DtkCompactArgs A, uint32_
     n_text++;
     sentB = true; posC = 0; text_tok0 = n_tok;
   };
+  // the next 32 positions' words are requested before this word's calls are worked through
+  uint32_t nE = bits32(bE, gb), nS = bits32(bS, gb), nP = bits32(bP, gb), nT = bits32(bT, gb), nU = bits32(bU, gb),
+           nR = bits32(A.rs_bits, (uint32_t)off);
   for (uint32_t q0 = 0; q0 <= len; q0 += 32u) {
     const uint32_t valid = lowmask(len + 1u - q0);
-    const uint32_t wE = bits32(bE, gb + q0) & valid, wS = bits32(bS, gb + q0) & valid, wP = bits32(bP, gb + q0) & valid;
-    const uint32_t wT = bits32(bT, gb + q0) & valid, wU = bits32(bU, gb + q0) & valid;
-    const uint32_t wR = q0 < len ? bits32(A.rs_bits, (uint32_t)off + q0) & lowmask(len - q0) : 0u;
+    const uint32_t wE = nE & valid, wS = nS & valid, wP = nP & valid, wT = nT & valid, wU = nU & valid;
+    const uint32_t wR = q0 < len ? nR & lowmask(len - q0) : 0u;
+    {
+      const uint32_t q1 = q0 + 32u <= len ? q0 + 32u : q0;  // (behind the document: this word again, unused)
+      nE = bits32(bE, gb + q1); nS = bits32(bS, gb + q1); nP = bits32(bP, gb + q1);
+      nT = bits32(bT, gb + q1); nU = bits32(bU, gb + q1);
+      nR = bits32(A.rs_bits, (uint32_t)off + (q1 < len ? q1 : 0u));
+    }
     uint32_t ev = wE | wS | wP | wT;
     while (ev) {
       const uint32_t b = (uint32_t)__ffs((int)ev) - 1u, m = 1u << b;
@@ -2530,7 +2543,6 @@ __global__ __launch_bounds__(256) void k_compact_small(DtkCompactArgs A, uint32_
     }
     Rw += (uint32_t)__popc(wR);
   }
-  const uint32_t tw = A.doc_tail[d];         // matrix.go:683-691
   if (tw & DTK_TAIL_S) sentence_end();
   if (tw & DTK_TAIL_E) text_end();
   if (st || n_tok != tok_n || n_sent != sent_n || n_text != text_n) {  // (see k_compact: the exact pass decides)
