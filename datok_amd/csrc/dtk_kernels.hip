@@ -1591,7 +1591,10 @@ __global__ __launch_bounds__(WAVE) void k_spec_walk(TRANS tr, DtkWalkArgs A, Dtk
 // must have arrived exactly there) or it is the chain's last lane (then it must have reached EOF, and no later lane
 // may have a record: the lane in front of such a record, which has none itself, finds the chain's last lane by
 // walking back).  The first lane that fails is the same one in both formulations.
-#define VERIFY_TB 1024u
+// (256 threads.  With 1024 -- 16 waves adding up before their atomics -- one long document verified faster still, but
+//  with three batches in flight the blocks have to wait for four free wave slots on every SIMD of one CU, which the
+//  other batches' walks, six waves per SIMD, rarely leave: 154 -> 143 GB/s.)
+#define VERIFY_TB 256u
 __global__ __launch_bounds__(VERIFY_TB) void k_spec_verify(DtkWalkArgs A, DtkSpecArgs S, uint32_t cmp_mask, uint32_t local_link) {
   if (S.go && *S.go == 0u) return;
   const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1663,7 +1666,7 @@ __global__ __launch_bounds__(VERIFY_TB) void k_spec_verify(DtkWalkArgs A, DtkSpe
   }
   const uint32_t dprev = __shfl_up(d, 1);
   const bool head = live && (lane_id() == 0 || dprev != d);
-  // A block whose 16 waves all lie inside one document adds up once more: the waves of a long document otherwise
+  // A block whose waves all lie inside one document adds up once more: the waves of a long document otherwise
   // queue their atomics at the same three addresses (one 64 MiB document: 4096 waves, 106 us of verification).
   __shared__ uint32_t s_d[VERIFY_TB / WAVE], s_v[VERIFY_TB / WAVE][4];
   const uint32_t wid = threadIdx.x >> 6;
@@ -2659,13 +2662,14 @@ __global__ __launch_bounds__(WAVE) void k_seg_scan(DtkCompactArgs A, const uint3
 // Each thread adds up a few consecutive documents, the 16 waves scan with shuffles, one barrier
 // links them.  With `fix` set it also does k_spec_fix's per-document step (one launch less on the
 // batch's critical path).
-__global__ __launch_bounds__(1024) void k_scan3(const uint64_t *ca, const uint64_t *cb, const uint64_t *cc,
+#define SCAN1_TB 1024u
+__global__ __launch_bounds__(SCAN1_TB) void k_scan3(const uint64_t *ca, const uint64_t *cb, const uint64_t *cc,
                                                 uint64_t *a, uint64_t *b, uint64_t *c, uint32_t n,
                                                 uint64_t *totals, const uint32_t *status, DtkSpecArgs S,
                                                 uint32_t *redo_out, uint32_t *n_bad, int fix, const uint32_t *skip_if) {
   if (skip_if && *skip_if != 0u) return;
-  __shared__ uint64_t wsum[3][16];
-  __shared__ uint32_t wfl[16];
+  __shared__ uint64_t wsum[3][SCAN1_TB / WAVE];
+  __shared__ uint32_t wfl[SCAN1_TB / WAVE];
   const uint32_t T = blockDim.x, tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
   const uint32_t per = (n + T - 1) / T;
   const uint32_t lo = tid * per < n ? tid * per : n;
@@ -2998,8 +3002,9 @@ extern "C" int dtk_launch_scan3(const uint64_t *ca, const uint64_t *cb, const ui
   hipStream_t s = (hipStream_t)stream;
   if (n_docs <= 8192u || !ws) {
     DtkSpecArgs none{};
-    // 1024 threads: the kernel's time is the threads' serial loops over their documents (512: +50 %)
-    hipLaunchKernelGGL(k_scan3, dim3(1), dim3(1024), 0, s, ca, cb, cc, a, b, c, n_docs, totals, status,
+    // 1024 threads: the kernel's time is the threads' serial loops over their documents (512: 23 instead of 16 us
+    // for 4096 documents, 256: 32 us)
+    hipLaunchKernelGGL(k_scan3, dim3(1), dim3(SCAN1_TB), 0, s, ca, cb, cc, a, b, c, n_docs, totals, status,
                        fix_spec ? *fix_spec : none, redo_out, n_bad, fix_spec ? 1 : 0, skip_if);
   } else {
     if (fix_spec) return -1;  // the caller runs k_spec_fix itself for that many documents
