@@ -11,4 +11,4 @@ timeout -k 10 300 python scripts/robust.py > gpurun_out/r02/robust.txt 2>&1
 timeout -k 10 200 python scripts/tiny_docs.py > gpurun_out/r02/tiny.txt 2>&1
 timeout -k 10 200 python scripts/big_stages.py 32 > gpurun_out/r02/big_stages.txt 2>&1
 timeout -k 10 200 python scripts/stages3.py 65536 >> gpurun_out/r02/big_stages.txt 2>&1
-tail -3 gpurun_out/r02/configs.txt gpurun_out/r02/robust.txt gpurun_out/r02/tiny.txt gpurun_out/r02/big_stages.txt
+for f in configs robust tiny big_stages; do tail -n 4 gpurun_out/r02/$f.txt; done
