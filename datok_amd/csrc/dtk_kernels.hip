@@ -2511,7 +2511,9 @@ __global__ __launch_bounds__(256) void k_compact_small(DtkCompactArgs A, uint32_
       nT = bits32(bT, gb + q1); nU = bits32(bU, gb + q1);
       nR = bits32(A.rs_bits, (uint32_t)off + (q1 < len ? q1 : 0u));
     }
-    uint32_t ev = wE | wS | wP | wT;
+    // (the START bits are looked up, not walked through: a token's first byte is the highest START bit below its
+    //  END bit -- in this word, or the last one of the words before: half the iterations of the divergent loop)
+    uint32_t ev = wE | wP | wT;
     while (ev) {
       const uint32_t b = (uint32_t)__ffs((int)ev) - 1u, m = 1u << b;
       ev &= ev - 1u;
@@ -2522,6 +2524,11 @@ __global__ __launch_bounds__(256) void k_compact_small(DtkCompactArgs A, uint32_
         if (is_matrix) { B = p; RB = R; }    // matrix.go:601 rewinds, datok.go:1019-1030 does not
       }
       if (wE & m) {                          // Token(offset, buf), token_writer.go:58-88
+        const uint32_t ms = wS & lowmask(b);
+        if (ms) {
+          const uint32_t sb = 31u - (uint32_t)__clz((int)ms);
+          cs = q0 + sb; Rcs = Rw + (uint32_t)__popc(wR & lowmask(sb));
+        }
         if (posC == 0 && nl_rule && p > B && txt[B] == '\n' && !init) posC--;
         init = false;
         posC += (int32_t)(Rcs - RB);
@@ -2542,7 +2549,10 @@ __global__ __launch_bounds__(256) void k_compact_small(DtkCompactArgs A, uint32_
         B = p; RB = R;
       }
       if (wP & m) sentence_end();            // matrix.go:574-575
-      if (wS & m) { cs = p; Rcs = R; }       // the next token starts here
+    }
+    if (wS) {  // the token that is under way at the end of this word started here
+      const uint32_t sb = 31u - (uint32_t)__clz((int)wS);
+      cs = q0 + sb; Rcs = Rw + (uint32_t)__popc(wR & lowmask(sb));
     }
     Rw += (uint32_t)__popc(wR);
   }
