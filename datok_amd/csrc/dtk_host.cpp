@@ -64,6 +64,7 @@ struct dtk_model {
   int kind = 0;
   int epsilon = 0, unknown = 0, identity = 0, final_state = 0, sigma_count = 0;
   uint32_t state_count = 0;
+  std::vector<uint16_t> col;   // symbol -> column of the device table (layout_matrix); empty: the symbol itself
   uint32_t dense_states = 0;   // double array laid out as a matrix (densify in build_datok): its states; 0: the pairs are walked
   uint64_t array_len = 0;
   uint32_t n_eps_states = 0, max_eps_chain = 0, unknown_used = 0;
@@ -169,8 +170,14 @@ static int upload(dtk_model *m, const void *tab, size_t tab_bytes) {
   HIP_TRY(hipMalloc(&m->d_tab, std::max<size_t>(tab_bytes, 16) + slack));
   HIP_TRY(hipMemset((char *)m->d_tab + tab_bytes, 0, slack));
   HIP_TRY(hipMemcpy(m->d_tab, tab, tab_bytes, hipMemcpyHostToDevice));
+  // (symbols as the device sees them: the column of the table they index, see layout_matrix)
+  auto colof = [&](int sym) -> uint32_t {
+    return (sym >= 0 && (size_t)sym < m->col.size()) ? m->col[(size_t)sym] : (uint32_t)sym;
+  };
+  uint16_t ascii_dev[256];
+  for (int i = 0; i < 256; i++) ascii_dev[i] = (uint16_t)colof(m->ascii[i]);
   HIP_TRY(hipMalloc((void **)&m->d_ascii, 256 * sizeof(uint16_t)));
-  HIP_TRY(hipMemcpy(m->d_ascii, m->ascii, 256 * sizeof(uint16_t), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(m->d_ascii, ascii_dev, 256 * sizeof(uint16_t), hipMemcpyHostToDevice));
   // the device's sorted rune list only holds runes >= 256 (the others go through the 256-entry table)
   size_t first = 0;
   while (first < m->sigma_runes.size() && m->sigma_runes[first] < 256u) first++;
@@ -179,7 +186,9 @@ static int upload(dtk_model *m, const void *tab, size_t tab_bytes) {
   HIP_TRY(hipMalloc((void **)&m->d_syms, std::max<size_t>(nr, 1) * sizeof(uint16_t)));
   if (nr) {
     HIP_TRY(hipMemcpy(m->d_runes, m->sigma_runes.data() + first, nr * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(m->d_syms, m->sigma_syms.data() + first, nr * sizeof(uint16_t), hipMemcpyHostToDevice));
+    std::vector<uint16_t> syms_dev(nr);
+    for (size_t i = 0; i < nr; i++) syms_dev[i] = (uint16_t)colof(m->sigma_syms[first + i]);
+    HIP_TRY(hipMemcpy(m->d_syms, syms_dev.data(), nr * sizeof(uint16_t), hipMemcpyHostToDevice));
   }
   m->device_bytes = tab_bytes + slack + 512 + nr * 6;
   m->sig.ascii = m->d_ascii;
@@ -188,11 +197,12 @@ static int upload(dtk_model *m, const void *tab, size_t tab_bytes) {
   m->sig.n_runes = (uint32_t)nr;
   // a net without identity symbol (-1, fomafile.go:88): unmapped runes get symbol 0, which has
   // no arcs (matrix.go:459), and no symbol ever equals the identity (matrix.go:478)
-  m->sig.identity = m->identity < 0 ? 0u : (uint32_t)m->identity;
+  m->sig.identity = m->identity < 0 ? 0u : colof(m->identity);
   m->tab.tab = m->d_tab;
-  m->tab.epsilon = (uint32_t)m->epsilon;
-  m->tab.unknown = (uint32_t)m->unknown;
-  m->tab.identity = (uint32_t)m->identity;
+  m->tab.epsilon = colof(m->epsilon);
+  m->tab.unknown = m->unknown < 0 ? (uint32_t)m->unknown : colof(m->unknown);
+  m->tab.identity = m->identity < 0 ? (uint32_t)m->identity : colof(m->identity);
+  if (m->tab.ident_guard != 0xFFFFFFFFu) m->tab.ident_guard = colof((int)m->tab.ident_guard);
   return DTK_OK;
 }
 
@@ -270,6 +280,30 @@ static int layout_matrix(dtk_model *m, const std::vector<uint32_t> &arr, uint64_
   const bool wide = (N + 1) > 0x7FFFu || getenv("DATOK_FORCE_WIDE") != nullptr;
   const uint32_t stride = (uint32_t)((S + 7) & ~7ull);
   const size_t cells_total = (size_t)(N + 1) * stride;
+  // Columns: the symbols of running text first -- blank, the lower-case letters by frequency, full stop, comma,
+  // newline, umlauts, digits, capitals --, so that the cells a row is mostly asked for share one or two cache lines
+  // (in file order the letters, the blank and the punctuation of a row lie in four or five).  Symbol 0 keeps
+  // column 0 (no arcs, matrix.go:459).  The device's symbol tables and special symbols are mapped in upload().
+  std::vector<uint16_t> &col = m->col;
+  col.assign((size_t)S, 0xFFFFu);
+  {
+    static const uint32_t order[] = {' ', 'e', 'n', 'i', 's', 'r', 'a', 't', 'd', 'h', 'u', 'l', 'c', 'g', 'm', 'o', 'b', 'w', 'f',
+                                     'k', 'z', 'p', 'v', '.', ',', '\n', 0xFC, 0xE4, 0xF6, 0xDF, 'j', 'y', 'x', 'q', '-', '\'', '"',
+                                     '0', '1', '2', '3', '4', '5', '6', '7', '8', '9', 'S', 'D', 'A', 'E', 'B', 'M', 'K', 'W', 'G',
+                                     'H', 'T', 'I', 'P', 'L', 'R', 'F', 'N', 'V', 'Z', 'U', 'O', 'J', 'C', ':', ';', '?', '!', '(', ')',
+                                     '/', '\t', '\r'};
+    uint32_t next_col = 1;
+    col[0] = 0;
+    if (!getenv("DATOK_FILE_COLUMNS"))
+      for (uint32_t r : order)
+        for (size_t i = 0; i < m->sigma_runes.size(); i++)
+          if (m->sigma_runes[i] == r) {
+            const uint32_t a = m->sigma_syms[i];
+            if (a > 0 && a < S && col[a] == 0xFFFFu) col[a] = (uint16_t)next_col++;
+          }
+    for (uint64_t a = 1; a < S; a++)
+      if (col[a] == 0xFFFFu) col[a] = (uint16_t)next_col++;
+  }
   // 15-bit state ids: uint32 cells with fused epsilon+rune entries (MatrixFusedTrans);
   // DATOK_NO_FUSED=1 keeps the plain uint16 table (for A/B measurements)
   const bool fused = !wide && !getenv("DATOK_NO_FUSED");
@@ -286,7 +320,7 @@ static int layout_matrix(dtk_model *m, const std::vector<uint32_t> &arr, uint64_
       if (tgt == 0) continue;
       if (tgt > N) return DTK_E_MODEL;
       if ((int)a == m->unknown) m->unknown_used = 1;
-      const size_t at = (size_t)newid[t] * stride + a;
+      const size_t at = (size_t)newid[t] * stride + col[a];
       if (wide) put(at, newid[tgt] | (x & DTK_FIRSTBIT));
       else put(at, newid[tgt] | ((x & DTK_FIRSTBIT) ? 0x8000u : 0u));
     }
@@ -302,7 +336,7 @@ static int layout_matrix(dtk_model *m, const std::vector<uint32_t> &arr, uint64_
         const uint32_t x2 = cell(a, e);
         const uint32_t tgt2 = x2 & ~DTK_FIRSTBIT;
         if (tgt2 == 0 || tgt2 > N) continue;
-        put((size_t)newid[t] * stride + a,
+        put((size_t)newid[t] * stride + col[a],
             0x80000000u | (newid[e] << 16) | newid[tgt2] | ((x2 & DTK_FIRSTBIT) ? 0x8000u : 0u));
       }
     }
