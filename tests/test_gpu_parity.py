@@ -625,9 +625,9 @@ print("VARIANT OK")
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"DATOK_LDS_BITS": "0"}, {"DATOK_SPLIT_START": "1"},
                                  {"DATOK_SPLIT_START": "1", "DATOK_LDS_BITS": "0"}, {"DATOK_CLEAR_KERNEL": "1"},
-                                 {"DATOK_COMPACT_FULL": "1", "DATOK_DEV_ROUNDS": "2"}],
+                                 {"DATOK_COMPACT_FULL": "1", "DATOK_DEV_ROUNDS": "2"}, {"DATOK_FILE_COLUMNS": "1"}],
                          ids=["no-lds-bitmaps", "split-start", "split-start+no-lds-bitmaps", "clear-kernel",
-                              "both-compactions+device-rounds"])
+                              "both-compactions+device-rounds", "file-column-order"])
 def test_kernel_variants_forced_by_environment(env, tmp_path):
     """The library runs the first pass as one launch that reports through the waves' LDS bitmaps, clears its
     accumulators in k_symbolize and launches what a batch's last run needed; the other paths (event bits straight to
