@@ -21,7 +21,9 @@
 #include "dtk_internal.h"
 
 #define WAVE 64
-#define DTK_WARM_TAG 64u  // how far behind a warm-up start an opening angle bracket is looked for
+#ifndef DTK_WARM_TAG
+#define DTK_WARM_TAG 64u
+#endif  // how far behind a warm-up start an opening angle bracket is looked for
 // knock-out builds for cost measurements (scripts/ko.sh): results are wrong, only timings mean something
 #ifndef DTK_KO
 #define DTK_KO 0
