@@ -818,6 +818,7 @@ struct dtk_batch {
   DtkSegIn *d_seg_in = nullptr;
   uint32_t n_segs = 0, seg_cap = 0;
   bool long_docs = false;            // some document has more than one segment
+  uint32_t max_doc_lanes = 0;        // lanes of the longest document (bounds the repair rounds)
   uint32_t *d_blk_doc = nullptr;     // document of the first byte of every 4 KiB input block
   // compaction: documents of at most small_max bytes go one per lane (k_compact_small), the others one per wave
   uint32_t small_max = 0, n_big = 0;
@@ -836,6 +837,7 @@ struct dtk_batch {
                                  // [8..9] as u32[4]: documents to repair after the first pass / after each device-side round
   uint32_t dev_rounds = 0;       // repair rounds enqueued ahead of time in the last run
   bool expect_repairs = false;   // the last run needed repairs: enqueue rounds ahead of time in the next one
+  uint32_t round_limit = 0xFFFFFFFFu;  // repair rounds from the host before the one-lane-per-document fallback (DATOK_ROUND_LIMIT)
   bool acc_primed = false;       // the accumulator block has been cleared whole once (k_symbolize clears it from then on)
   uint64_t epoch = 0;            // number of the run (k_symbolize marks runs that saw invalid UTF-8 with it)
   bool expect_eot = false;       // the last run had documents with EOT calls: launch their compaction kernel with the run
@@ -925,6 +927,7 @@ extern "C" int dtk_batch_create(uint64_t max_bytes, uint32_t max_docs, dtk_batch
   } while (0)
   B_TRY(hipGetDevice(&b->device));
   B_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+  if (const char *e = getenv("DATOK_ROUND_LIMIT")) b->round_limit = (uint32_t)atoi(e);
   const uint64_t pad = 256;
   B_TRY(hipMalloc((void **)&b->d_text_own, max_bytes + pad));
   B_TRY(hipMalloc((void **)&b->d_off_own, ((uint64_t)max_docs + 1) * 8));
@@ -1129,10 +1132,12 @@ static int plan_lanes(dtk_batch *b) {
   // segments of DTK_SEG_LANES lanes: the unit of k_compact for documents with many lanes
   std::vector<uint32_t> seg_doc, seg_lane0, seg_nl, doc_seg0((size_t)nd + 1);
   b->long_docs = false;
+  b->max_doc_lanes = 0;
   for (uint32_t d = 0; d < nd; d++) {
     doc_seg0[d] = (uint32_t)seg_doc.size();
     const uint32_t L0 = chunk_off[d], L1 = chunk_off[d + 1];
     if (L1 - L0 > DTK_SEG_LANES) b->long_docs = true;
+    b->max_doc_lanes = std::max(b->max_doc_lanes, L1 - L0);
     for (uint32_t L = L0; L < L1; L += DTK_SEG_LANES) {
       seg_doc.push_back(d);
       seg_lane0.push_back(L);
@@ -1474,6 +1479,10 @@ static int finish(dtk_batch *b) {
       hipStream_t s = b->stream;
       DtkWalkArgs w = walk_args(b);
       uint32_t *n_bad = (uint32_t *)(b->d_totals + 8) + b->dev_rounds;  // (the counter the scan / compaction looked at)
+      // Every round verifies at least one more lane of every broken document (the first bad lane started from a true
+      // state), so the longest document's lane count bounds the rounds.  Should they run out all the same, the batch
+      // is walked again with one lane per document -- no speculation, nothing to repair.
+      const uint32_t max_rounds = b->max_doc_lanes + 16u;
       while (left != 0) {
         b->repair_rounds++;
         DtkSpecArgs sp = spec_args(b, true);
@@ -1482,7 +1491,16 @@ static int finish(dtk_batch *b) {
         if (rc != DTK_OK) return rc;
         HIP_TRY(hipMemcpyAsync(&left, n_bad, 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        if (b->repair_rounds > 1000000u) return DTK_E_STATE;
+        if (left != 0 && (b->repair_rounds > max_rounds || b->repair_rounds >= b->round_limit)) {
+          const uint32_t rounds = b->repair_rounds, keep = b->cfg_chunk;
+          b->cfg_chunk = 0; b->plan_valid = false;
+          rc = dtk_batch_run(m, b, b->last_flags);
+          if (rc == DTK_OK) rc = finish(b);
+          b->cfg_chunk = keep; b->plan_valid = false;
+          b->repair_rounds = rounds; b->totals.repair_rounds = rounds;
+          b->expect_repairs = true;
+          return rc;
+        }
       }
       if (dtk_launch_scan3(b->d_tok_cnt, b->d_sent_cnt, b->d_text_cnt, b->d_tok_off, b->d_sent_off, b->d_text_off,
                          b->n_docs, b->d_totals, b->d_status, b->d_scan_ws, nullptr, nullptr, nullptr, nullptr, s))

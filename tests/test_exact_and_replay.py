@@ -193,3 +193,16 @@ int main(int argc, char **argv) {
         got = [tuple([ln.split()[0]] + [int(x) for x in ln.split()[1:]]) for ln in r.stdout.decode().splitlines()]
         exp = [c[:3] if c[0] == "T" else c for c in _oracle_calls(om, doc)]
         assert got == exp, path
+
+
+@pytest.mark.gpu
+def test_crafted_models_through_the_two_launch_first_pass():
+    """DATOK_SPLIT_START=1 (start records and chunk walk as two launches, windows chained from the first pass on:
+    what a batch with chunks of more than 256 bytes runs).  With the crafted double array and 16-byte chunks the
+    repair rounds of that path do not converge; they are bounded by the lanes of the longest document, and the batch
+    is then walked with one lane per document (dtk_host.cpp finish()).  It used to spin for a million rounds."""
+    import sys
+    e = dict(os.environ); e["DATOK_SPLIT_START"] = "1"
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", "-k",
+                        "not two_launch", os.path.abspath(__file__)], capture_output=True, env=e, timeout=600, cwd=ROOT)
+    assert r.returncode == 0 and b" passed" in r.stdout, (r.stdout.decode()[-1500:], r.stderr.decode()[-500:])

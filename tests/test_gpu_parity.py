@@ -625,15 +625,17 @@ print("VARIANT OK")
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"DATOK_LDS_BITS": "0"}, {"DATOK_SPLIT_START": "1"},
                                  {"DATOK_SPLIT_START": "1", "DATOK_LDS_BITS": "0"}, {"DATOK_CLEAR_KERNEL": "1"},
-                                 {"DATOK_COMPACT_FULL": "1", "DATOK_DEV_ROUNDS": "2"}, {"DATOK_FILE_COLUMNS": "1"}],
+                                 {"DATOK_COMPACT_FULL": "1", "DATOK_DEV_ROUNDS": "2"}, {"DATOK_FILE_COLUMNS": "1"},
+                                 {"DATOK_ROUND_LIMIT": "1"}],
                          ids=["no-lds-bitmaps", "split-start", "split-start+no-lds-bitmaps", "clear-kernel",
-                              "both-compactions+device-rounds", "file-column-order"])
+                              "both-compactions+device-rounds", "file-column-order", "one-lane-fallback"])
 def test_kernel_variants_forced_by_environment(env, tmp_path):
     """The library runs the first pass as one launch that reports through the waves' LDS bitmaps, clears its
     accumulators in k_symbolize and launches what a batch's last run needed; the other paths (event bits straight to
     memory, start records and walk as two launches -- which is also what repair rounds use --, a clear kernel, both
-    compaction kernels and device-side repair rounds with every run) must give the same offsets.  The switches are
-    read once per process."""
+    compaction kernels and device-side repair rounds with every run; the walk with one lane per document that takes
+    over when the repair rounds run out, here after the first) must give the same offsets.  The switches are read
+    once per process."""
     import subprocess
     script = tmp_path / "variant.py"
     script.write_text(_VARIANT_SCRIPT)
