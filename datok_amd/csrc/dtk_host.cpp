@@ -1491,6 +1491,23 @@ static int finish(dtk_batch *b) {
         if (rc != DTK_OK) return rc;
         HIP_TRY(hipMemcpyAsync(&left, n_bad, 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
+        if (left != 0 && getenv("DATOK_DEBUG_REPAIR") && b->repair_rounds < 12) {
+          std::vector<uint32_t> redo(b->n_docs), chunk_off(b->n_docs + 1);
+          HIP_TRY(hipMemcpy(redo.data(), b->d_redo, (size_t)b->n_docs * 4, hipMemcpyDeviceToHost));
+          HIP_TRY(hipMemcpy(chunk_off.data(), b->d_chunk_off, ((size_t)b->n_docs + 1) * 4, hipMemcpyDeviceToHost));
+          for (uint32_t d = 0, shown = 0; d < b->n_docs && shown < 3; d++)
+            if (redo[d] != 0xFFFFFFFFu) {
+              const uint32_t L0 = chunk_off[d], L1 = chunk_off[d + 1], n = std::min<uint32_t>(L1 - L0, 24u);
+              std::vector<DtkLaneState> st(n), en(n);
+              HIP_TRY(hipMemcpy(st.data(), b->d_lane_start + L0, n * sizeof(DtkLaneState), hipMemcpyDeviceToHost));
+              HIP_TRY(hipMemcpy(en.data(), b->d_lane_end + L0, n * sizeof(DtkLaneState), hipMemcpyDeviceToHost));
+              fprintf(stderr, "round %u: %u broken; doc %u lanes %u redo from lane %u:", b->repair_rounds, left, d, L1 - L0, redo[d] - L0);
+              for (uint32_t k = 0; k < n; k++)
+                fprintf(stderr, " [%u: s %d/%u/%x e %d/%u/%x]", k, (int)st[k].p, st[k].t, st[k].flags, (int)en[k].p, en[k].t, en[k].flags);
+              fprintf(stderr, "\n");
+              shown++;
+            }
+        }
         if (left != 0 && (b->repair_rounds > max_rounds || b->repair_rounds >= b->round_limit)) {
           const uint32_t rounds = b->repair_rounds, keep = b->cfg_chunk;
           b->cfg_chunk = 0; b->plan_valid = false;

@@ -496,7 +496,11 @@ struct EventSink {
   // has_tok: the current text has a token (else the reference panics in position modes)
   template <bool IS_MATRIX>
   __device__ __forceinline__ void eot(uint32_t /*bs*/, uint32_t p, bool with_sentence, bool has_tok) {
-    if (!in_closing(p)) { dropped = 1; return; }
+    // (The double array has no upper bound here: it keeps its window over an EOT, so the EOT is no sync point and a
+    //  lane may fire one behind its stop position and then backtrack to a token end in front of it -- the construct
+    //  of the exact pass.  The fire is the lane's: counted, its bit set; the successor's second fire finds the bit
+    //  and flags the document.  Dropped, it made the lane fail its check in every repair round.)
+    if (IS_MATRIX ? !in_closing(p) : p <= lo) { dropped = 1; return; }
     c_text++;
     c_sev += with_sentence ? 1u : 0u;
     e_pos = p; e_tok = c_tok;

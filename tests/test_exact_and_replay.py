@@ -198,9 +198,10 @@ int main(int argc, char **argv) {
 @pytest.mark.gpu
 def test_crafted_models_through_the_two_launch_first_pass():
     """DATOK_SPLIT_START=1 (start records and chunk walk as two launches, windows chained from the first pass on:
-    what a batch with chunks of more than 256 bytes runs).  With the crafted double array and 16-byte chunks the
-    repair rounds of that path do not converge; they are bounded by the lanes of the longest document, and the batch
-    is then walked with one lane per document (dtk_host.cpp finish()).  It used to spin for a million rounds."""
+    what a batch with chunks of more than 256 bytes runs, and what every repair round runs).  A double-array lane
+    may fire an EOT behind its stop position and then backtrack to a token end in front of it; dropped as out of
+    its window, that event made the lane fail its check in every repair round (EventSink::eot) -- the rounds spun
+    for 90 s.  Every test of this file through that path."""
     import sys
     e = dict(os.environ); e["DATOK_SPLIT_START"] = "1"
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", "-k",
