@@ -418,7 +418,9 @@ static int build_datok(dtk_model *m, const std::vector<uint8_t> &raw) {
   // epsilon cells -- under the double array's own rules for EOT (datok.go:1019-1030; walk_fused<.., IS_MATRIX =
   // false>, compaction and replay go by m->kind).  DATOK_NO_DENSE=1 keeps the pairs (DaTrans; what the tests of that
   // path set).
-  if (!getenv("DATOK_NO_DENSE")) {
+  // (only with fused cells: the lean loop and the fused general loop carry the double array's EOT rules; the plain
+  //  matrix encodings that DATOK_NO_FUSED / DATOK_FORCE_WIDE select for the tests are not run with them)
+  if (!getenv("DATOK_NO_DENSE") && !getenv("DATOK_NO_FUSED") && !getenv("DATOK_FORCE_WIDE")) {
     std::vector<uint32_t> arr;
     uint64_t n_dense = 0;
     // one step of datok.go:888-901 + 1055-1063 from state s0 on symbol a: 0 = no arc, else target | FIRSTBIT if
