@@ -2069,6 +2069,10 @@ __device__ __forceinline__ void compact_unit(const DtkCompactArgs &A, uint32_t s
       const uint32_t tbase = text_first ? base_mine : (mPrevTF ? baseFrom_t : cBase);
       const int32_t rend = (int32_t)(R - tbase);
       const int32_t rstart = rend - (int32_t)(R - startR);
+      // NEWLINE_AFTER_EOT is modelled as one shift per text, but token_writer.go:66-68 fires whenever posC == 0 and the
+      // buffer starts with a newline: a token that ends at offset 0 (it began at -1: a tokenizer that makes a token
+      // of the newline itself) may make it fire again.  Left to the exact pass.
+      if (nl_rule && isEnd && rend == 0) status |= ST_INTERNAL;
 
       // end offset of the last token below this lane / at or below it
       const int32_t rendPrev_t = __shfl(rend, jp);
@@ -2256,6 +2260,7 @@ __device__ __forceinline__ void compact_unit(const DtkCompactArgs &A, uint32_t s
         // The rows go through LDS (four 16-bit fields relative to the tile, one 8-byte write) and leave as runs of
         // consecutive rows below: written from here, lane by lane, every 4-byte store of the wave lands in another
         // cache line -- 64 address cycles per store instruction, which is what this kernel's time was made of.
+        if (nl_rule && R == base) status |= ST_INTERNAL;  // (a token that ends at offset 0: see the heavy rounds)
         const uint32_t li = tokB + j;  // row within the tile
         const uint64_t k = tok_base + cTE + li;
         const uint32_t sbef = pB + (uint32_t)__popc(wP & lowmask(b));
