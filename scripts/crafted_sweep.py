@@ -24,8 +24,11 @@ for kind in ("datok", "matok"):
         path = "/tmp/crafted_%s_%d.%s" % (kind, triple, kind)
         open(path, "wb").write(blob)
         tok, om = datok_amd.load_tokenizer_file(path), O.Model(raw=gzip.decompress(blob))
-        for seed in (5, 6, 7):
-            docs = craft.documents(np.random.default_rng(seed))
+        for seed in (5, 6, 7, 105, 106):
+            docs = craft.documents(np.random.default_rng(seed % 100))
+            if seed >= 100:  # long documents (segments of 64 lanes at 16-byte chunks): 40 short ones glued together
+                rng = np.random.default_rng(seed)
+                docs = [b"".join(docs[int(i)] for i in rng.integers(0, len(docs), size=40)) for _ in range(24)]
             text, off = corpus.concat_docs(docs)
             for chunk in (16, 17, 24, 33, 64, 128):
                 for warm in (0, 2, 8, 32):
@@ -37,6 +40,13 @@ for kind in ("datok", "matok"):
                                 b.run(tok, flags)
                                 res, tot = b.result(), b.totals()
                                 assert_batch_equals_oracle(om, res, text, off, flags)
+                                if chunk in (16, 33) and warm == 2:  # the writer's bytes, rendered on the device
+                                    for bits in (3, 15):
+                                        data, o = b.render(bits | flags)
+                                        for d, doc in enumerate(docs):
+                                            exp, est = om.transduce(doc, bits | flags)
+                                            if est == 0 and not (int(res.status[d]) & ~datok_amd.ST_EMPTY_TEXT):
+                                                assert data[int(o[d]):int(o[d + 1])] == exp, (kind, triple, seed, chunk, bits, d, doc)
                                 n_runs += 1
                                 fallbacks += tot["chunk_bytes"] != chunk
                                 max_rounds = max(max_rounds, tot["repair_rounds"])
