@@ -489,6 +489,10 @@ struct EventSink {
     c_tok++;
     c_sent += sent_first ? 1u : 0u;
     if (p <= tp) st |= ST_IRREGULAR;
+    // The double array keeps its window over an EOT: a token may be flushed AFTER the EOT's SentenceEnd / TextEnd and
+    // end BEFORE it (the walk backtracked behind the EOT; if the retry then reads the EOT as an ordinary rune,
+    // matrix.go:555 / datok.go, nothing fires twice).  Calls out of position order: the exact pass.
+    if (!IS_MATRIX && last_eot_p != 0xFFFFFFFFu && p < last_eot_p) st |= ST_IRREGULAR;
     put(EVB_END, p);
     put(EVB_START, tp);
   }
@@ -530,9 +534,11 @@ struct EventSink {
     const uint32_t G = gbr + pos;
     __hip_atomic_fetch_or(&lds[kind * lw + (G >> 5)], 1u << (G & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
+  template <bool IS_MATRIX>
   __device__ __forceinline__ void token_first(uint32_t tp, uint32_t p, bool sent_first) {
     c_tok++;
     c_sent += sent_first ? 1u : 0u;
+    if (!IS_MATRIX && last_eot_p != 0xFFFFFFFFu && p < last_eot_p) st |= ST_IRREGULAR;  // (see token())
     put_first(EVB_END, p);
     put_first(EVB_START, tp);
   }
@@ -558,6 +564,8 @@ struct EventSink {
   __device__ __forceinline__ void tail(uint32_t /*bs*/, uint32_t p, bool sentence_end, bool text_end, bool has_tok) {
     tail_<IS_MATRIX>(p, sentence_end, text_end, has_tok);
   }
+  // calls that the position-indexed bitmaps cannot order
+  __device__ __forceinline__ void out_of_order() { st |= ST_IRREGULAR; }
   __device__ __forceinline__ void flush() {}
 };
 
@@ -728,7 +736,10 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
     const bool flush_eps = succ && is_eps && p > tp;                       // matrix.go:565-572
     const bool sent_eps = succ && is_eps && p <= tp;                       // matrix.go:573-576
     const bool advance = succ && !is_eps;                                  // matrix.go:579-591
-    const bool eot_now = (advance || comp) && eot;                         // matrix.go:593-605
+    // matrix.go:593-605: after ANY successful step while `eot` is set.  It is set by the rune just read, cleared by a
+    // retry (:555) and by the next rune -- so an epsilon step sees it only in the EOF drain behind a hard fail on a
+    // trailing EOT (the hard-fail branch leaves it set, :499-552, and no rune follows to clear it).
+    const bool eot_now = (succ || comp) && eot;
 
     if (hardfail || my_steps > cap) {  // rare
       if (hardfail) {  // drop what is buffered as a token, restart at state 1
@@ -750,20 +761,23 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
     has_tok = has_tok || flush;
     // consume the rune (for a fused cell: from the epsilon target, right after its rewind, so
     // the rune is the first of the window)
-    const bool skip = (advance && p == tp && nontoken) || (comp && nontoken);  // matrix.go:584-588
+    // (a fused cell's rune is the first of its token if the epsilon half flushed, or if the token was empty; after a
+    //  backtrack to a slot BEHIND the token start -- bufft > buffc, the reference's own odd case -- it is neither)
+    const bool skip = (advance && p == tp && nontoken) || (comp && nontoken && p >= tp);  // matrix.go:584-588
     const uint32_t p_old = p;
     p = (advance || comp) ? p + w : p;
-    tp = skip ? p : (comp ? p_old : tp);
+    tp = skip ? p : (flush_c ? p_old : tp);  // (the epsilon half of a fused cell rewinds only if it flushed)
     // the EOT fires a SentenceEnd unless one is pending (after the epsilon half of a fused cell)
-    const bool eot_sent = !(flush_c ? false : (sent_c ? true : sentence_end));
+    const bool eot_sent = !((flush_c || flush_eps) ? false : ((sent_c || sent_eps) ? true : sentence_end));
     sentence_end = eot_now ? true : (flush ? false : ((sent_eps || sent_c) ? true : sentence_end));
     text_end = eot_now ? true : (flush ? false : text_end);
     // retries keep the rune, everything else fetches a new one
     t0 = backtrack ? eps_t : t0; aux0 = backtrack ? eps_aux : aux0;
     p = backtrack ? eps_p : p;
     a = backtrack ? epsilon : (retry_unknown ? unknown : a);
-    eot = retry_unknown ? false : eot;  // matrix.go:555: a retry forgets that the rune was EOT
+    eot = (retry_unknown || backtrack) ? false : eot;  // matrix.go:555: a retry forgets that the rune was EOT
     newchar = succ || hardfail || comp;
+    eot = eot_now ? false : eot;  // matrix.go:594
     const bool rewind = flush || (IS_MATRIX && eot_now);  // matrix.go:601 vs datok.go:1019-1030
     eps_t = (backtrack || rewind || comp) ? 0u : eps_t;
     if (TRANS::FUSED) {
@@ -776,15 +790,21 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
     // a fused cell rewinds before its rune: that rewind is at p_old, never the end of the chunk
     const bool rewind_end = (flush && !comp) || (IS_MATRIX && eot_now);
     const bool long_win = hi - bs > DTK_WINDOW_BYTES;  // overflowed for certain: the lane stops (see walk_fused)
-    if (eot_now || (rewind && hi - bs > DTK_WINDOW) || (rewind_end && MODE != MODE_DOC && p >= stop_pos) || long_win) {
+    // (a hard fail on the document's last rune, an EOT: `eot` stays set for the EOF drain, and a start record has no
+    //  place for it -- the lane that read the rune runs the drain itself)
+    const bool at_stop = rewind_end && MODE != MODE_DOC && p >= stop_pos && !(hardfail && eot && p >= len);
+    if (eot_now || (rewind && hi - bs > DTK_WINDOW) || at_stop || long_win) {
       if (eot_now) {
+        // (fired by an epsilon step -- the stale `eot` -- the TextEnd follows a Token that ends at the same position:
+        //  rows in call order, the exact pass)
+        if (is_eps && MODE != MODE_START) sink.out_of_order();
         // (the epsilon half of a fused cell has rewound the window to p_old before its rune was read)
         if (MODE != MODE_START) sink.template eot<IS_MATRIX>(flush_c ? p_old : bs, p, eot_sent, has_tok);
         has_tok = false;  // TextEnd: pos = pos[:0] (token_writer.go:158)
       }
       if (rewind) {
         if (hi - bs > DTK_WINDOW && count_runes(s, bs, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
-        if (rewind_end && MODE != MODE_DOC && p >= stop_pos) {
+        if (at_stop) {
           fin.p = p; fin.t = t; fin.aux = aux;
           fin.flags = (sentence_end ? LANE_F_SENT : 0u) | (text_end ? LANE_F_TEXT : 0u) |
                       (ok ? LANE_F_OK : 0u);
@@ -868,6 +888,9 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
   // The entry the next lookup is made with: the stream entry of the rune at p -- or, right after a backtrack,
   // the bare epsilon symbol: width 0, so that iteration consumes nothing and reads no rune (matrix.go:487-497).
   uint32_t e = row[p - wb7];
+  // `eot` of the reference survives a hard fail (matrix.go:499-552 does not clear it; the next rune does): if that rune
+  // was the document's last, the first successful epsilon step of the EOF drain fires the EOT's SentenceEnd / TextEnd
+  bool eot_stale = false;
 
   // Reader at EOF before a rune is read (matrix.go:650-668): epsilon arcs are taken as long as the state has one
   // (here, on the spot: one lookup each); then the remembered epsilon state is popped -- the walk goes on from
@@ -892,6 +915,20 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
         F |= 1u;                                                                                              \
       }                                                                                                       \
       t = x_ & 0x7FFFu;                                                                                       \
+      if (eot_stale && !done) { /* matrix.go:593-605 behind the first successful step, see the hard-fail block */ \
+        eot_stale = false;                                                                                    \
+        /* (a TextEnd behind a Token that ends at the same position: rows in call order, the exact pass) */   \
+        if (MODE != MODE_START) sink.out_of_order();                                                          \
+        if (MODE != MODE_START) sink.template eot<IS_MATRIX>(bs, p, (F & 1u) == 0u, (F & 8u) != 0);           \
+        F = (F & 4u) | 3u;                                                                                    \
+        if (IS_MATRIX) {                                                                                      \
+          eps_t = 0; tp = p; bs = p;                                                                          \
+          if (MODE != MODE_DOC && p >= stop_pos) {                                                            \
+            fin.p = p; fin.t = t; fin.aux = 0; fin.flags = (F & 3u) | (init.flags & LANE_F_OK);               \
+            done = true;                                                                                      \
+          }                                                                                                   \
+        }                                                                                                     \
+      }                                                                                                       \
       if (ov_) { st |= ST_STEP_LIMIT; done = true; }                                                          \
     }                                                                                                         \
     if (!done) {                                                                                              \
@@ -946,8 +983,10 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
     //  the predicate from 0/1 integers in vector registers, seven instructions instead of two.)
     const unsigned long long m_comp = __builtin_amdgcn_ballot_w64((int32_t)x < 0),
                              m_adv = m_comp | (__builtin_amdgcn_ballot_w64((int32_t)x > 0) & ~__builtin_amdgcn_ballot_w64(w == 0u));
-    const unsigned long long m_skip =
-        __builtin_amdgcn_ballot_w64((x & 0x8000u) != 0u) & (m_comp | (m_adv & __builtin_amdgcn_ballot_w64(p == tp)));
+    // (a fused cell's rune is the first of its token unless the walk has backtracked to a slot BEHIND the token
+    //  start -- bufft > buffc, the reference's own odd case: then its epsilon half neither flushes nor rewinds)
+    const unsigned long long m_skip = __builtin_amdgcn_ballot_w64((x & 0x8000u) != 0u) &
+                                      ((m_comp & ~__builtin_amdgcn_ballot_w64(p < tp)) | (m_adv & __builtin_amdgcn_ballot_w64(p == tp)));
     uint32_t en_n;
     {
       const uint32_t pn_n = p_n + ((e_n >> DTK_SYM_W_SHIFT) & 7u);
@@ -971,7 +1010,7 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
     const uint32_t tp_old = tp, F_old = F;
     if (MODE != MODE_START && !(DTK_KO & 1)) {
       if (FIRST) {
-        if (flush && !beyond) sink.token_first(tp, p, ((F ^ 4u) & 7u) != 0);
+        if (flush && !beyond) sink.template token_first<IS_MATRIX>(tp, p, ((F ^ 4u) & 7u) != 0);
         if (sentE && !beyond) sink.sentence_first(p, (F & 8u) != 0);
       } else {
         if (flush) sink.template token<IS_MATRIX>(bs, tp, p, ((F ^ 4u) & 7u) != 0);
@@ -983,7 +1022,7 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
     F = flush ? 12u : (F | (sentE ? 1u : 0u));
     bs = flush ? p_old : bs;
 
-    tp = (comp || flush) ? p_old : tp;
+    tp = flush ? p_old : tp;  // (a fused cell with p <= tp takes its epsilon arc without a rewind)
     tp = __builtin_amdgcn_inverse_ballot_w64(m_skip) ? pn : tp;
     // the epsilon slot: dropped by a backtrack and by every epsilon step; a fused cell remembers the state it
     // read its rune in (the epsilon target, at p_old) if that state has an epsilon arc
@@ -1017,12 +1056,14 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
             if (p <= tp) { p = pn; }  // matrix.go:515-516
             if (p < tp) st |= ST_BAD_OFFSET;  // Token(bufft, buffer[:buffc]) with bufft > buffc
             e = p == pn ? e_next : e_cur;     // the rune at p (read again if it was not consumed)
+            eot_stale = p == pn && p >= len && ((e_cur >> DTK_SYM_CLS_SHIFT) & 3u) == 1u;
             if (MODE != MODE_START) sink.template token<IS_MATRIX>(bs, tp, p, ((F ^ 4u) & 7u) != 0);
             F = 12u;
             if (hi - bs > DTK_WINDOW && count_runes(s, bs, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
             t = tr.start; eps_t = 0;
             tp = p; bs = p;
-            if (MODE != MODE_DOC && p >= stop_pos) {
+            // (with a stale `eot` the lane goes on into the EOF drain itself: a start record has no place for it)
+            if (MODE != MODE_DOC && p >= stop_pos && !eot_stale) {
               fin.p = p; fin.t = t; fin.aux = 0;
               fin.flags = (init.flags & LANE_F_OK);
               done = true;
@@ -1217,6 +1258,7 @@ struct ExactSink {
     if (!sentence_end_) sentence_end(arg);       // matrix.go:683-684 / datok.go:1118-1119
     if (!text_end_) text_end(arg);               // matrix.go:690-691 / datok.go:1126-1127
   }
+  __device__ __forceinline__ void out_of_order() {}  // (call order is what this sink records)
 };
 
 template <typename TRANS, bool IS_MATRIX>

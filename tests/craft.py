@@ -46,8 +46,12 @@ def _sigma_bytes():
 
 
 def matok(triple=False) -> bytes:
-    arcs = _automaton(triple)
-    n, s = max(arcs), len(SIGMA)
+    return matok_from(_automaton(triple))
+
+
+def matok_from(arcs) -> bytes:
+    """The `.matok` image of an arc table  state -> {symbol: (target, nontoken)}  (states 1..n, 1 = start)."""
+    n, s = max(max(arcs), max(to for row in arcs.values() for to, _ in row.values())), len(SIGMA)
     arr = [0] * ((n + 1) * s)
     for t, row in arcs.items():
         for a, (to, nontoken) in row.items():
@@ -58,8 +62,12 @@ def matok(triple=False) -> bytes:
 
 
 def datok(triple=False) -> bytes:
-    arcs = _automaton(triple)
-    n, s = max(arcs), len(SIGMA)
+    return datok_from(_automaton(triple))
+
+
+def datok_from(arcs) -> bytes:
+    """The `.datok` image of the same kind of arc table (every arc slot "separate")."""
+    n, s = max(max(arcs), max(to for row in arcs.values() for to, _ in row.values())), len(SIGMA)
     size = n + 1 + (n + 1) * s
     base = [0] * (size + s + 2)
     check = [0] * (size + s + 2)
