@@ -448,7 +448,7 @@ struct EventSink {
   uint32_t w0;         // global word of LDS word 0
   uint32_t *tailw;     // the document's tail word
   uint32_t lo, hi;     // window
-  uint32_t last_s_p;   // position of the last epsilon SentenceEnd
+  uint32_t last_s_p1;  // position of the last epsilon SentenceEnd, plus one (0: none)
   uint32_t last_eot_p; // position of the last EOT pair
   uint32_t st;
   uint32_t dropped;
@@ -462,7 +462,7 @@ struct EventSink {
     g = A.bits; gw = A.bit_words; gb = (uint32_t)DTK_EV_BIT(off, d); tailw = A.doc_tail ? A.doc_tail + d : nullptr;
     lds = (dtk_lds_u32 *)lds_bits; lw = lds_bits ? lds_words : 0u; w0 = word0; gbr = gb - (word0 << 5);
     lo = wlo; hi = whi;
-    last_s_p = last_eot_p = 0xFFFFFFFFu; st = 0; dropped = 0;
+    last_s_p1 = 0u; last_eot_p = 0xFFFFFFFFu; st = 0; dropped = 0;
     c_tok = c_sent = c_text = 0;
     c_sev = 0; e_pos = 0xFFFFFFFFu; e_tok = 0;
   }
@@ -520,8 +520,8 @@ struct EventSink {
     if (!in_opening(p)) { dropped = 1; return; }
     c_sev++;
     if (has_tok) c_sent++; else st |= ST_EMPTY_TEXT;
-    if (p == last_s_p) st |= ST_IRREGULAR;
-    last_s_p = p;
+    if (p < last_s_p1) st |= ST_IRREGULAR;  // twice at one position, or behind a backtrack: not in position order
+    last_s_p1 = p + 1u;
     put(EVB_SEPS, p);
   }
   // First pass (k_spec_both), events before the lane's stop position: the window is open-ended and the position lies
@@ -545,8 +545,8 @@ struct EventSink {
   __device__ __forceinline__ void sentence_first(uint32_t p, bool has_tok) {
     c_sev++;
     if (has_tok) c_sent++; else st |= ST_EMPTY_TEXT;
-    if (p == last_s_p) st |= ST_IRREGULAR;
-    last_s_p = p;
+    if (p < last_s_p1) st |= ST_IRREGULAR;  // twice at one position, or behind a backtrack: not in position order
+    last_s_p1 = p + 1u;
     put_first(EVB_SEPS, p);
   }
   // final SentenceEnd / TextEnd -- matrix.go:683-691

@@ -20,44 +20,11 @@ from parity import assert_batch_equals_oracle  # noqa: E402
 
 n_auto = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-SYMS = [craft.A, craft.B, craft.E, craft.SP, craft.DOT, craft.NL]
-
-
-def automaton(rng):
-    n = int(rng.integers(3, 9))
-    arcs = {}
-    for t in range(1, n + 1):
-        row = {}
-        for a in SYMS:
-            if rng.random() < 0.55:
-                row[a] = (int(rng.integers(1, n + 1)), bool(rng.random() < (0.6 if a in (craft.SP, craft.NL, craft.E) else 0.1)))
-        if t < n and rng.random() < 0.45:          # epsilon arcs only upwards: no cycles (the loaders reject those)
-            row[craft.EPS] = (int(rng.integers(t + 1, n + 1)), False)
-        if rng.random() < 0.08:
-            row[craft.UNKNOWN] = (int(rng.integers(1, n + 1)), False)
-        if rng.random() < 0.08:
-            row[craft.IDENTITY] = (int(rng.integers(1, n + 1)), bool(rng.random() < 0.3))
-        arcs[t] = row
-    if not arcs[1]:
-        arcs[1][craft.A] = (1, False)
-    return arcs
-
-
-def documents(rng, n=160):
-    alpha = "aab b \x04.\n" + ("xä" if rng.random() < 0.5 else "")   # x, a-umlaut: not in the sigma (identity / unknown)
-    docs = [b"", b"a", b"\x04", b" ", b"a\x04a", b"a. b.\x04\n\na"]
-    for _ in range(n):
-        k = int(rng.integers(0, 90))
-        docs.append("".join(alpha[int(i)] for i in rng.integers(0, len(alpha), size=k)).encode())
-    long_ = [b"".join(docs[int(i)] for i in rng.integers(0, len(docs), size=30)) for _ in range(6)]
-    return docs + long_
-
-
 runs = docs_checked = 0
 for seed in range(first, first + n_auto):
     rng = np.random.default_rng(seed)
-    arcs = automaton(rng)
-    docs = documents(rng)
+    arcs = craft.random_automaton(rng)
+    docs = craft.random_documents(rng)
     text, off = corpus.concat_docs(docs)
     for kind in ("matok", "datok"):
         blob = getattr(craft, kind + "_from")(arcs)

@@ -100,3 +100,36 @@ def documents(rng, n=400, max_len=60):
         k = int(rng.integers(0, max_len))
         docs.append("".join(ALPHABET[int(i)] for i in rng.integers(0, len(ALPHABET), size=k)).encode())
     return docs
+
+
+def random_automaton(rng):
+    """A random arc table for matok_from / datok_from (scripts/fuzz_automata.py, tests/test_exact_and_replay.py):
+    3-8 states, arcs on the six sigma symbols, now and then on `unknown` / `identity`; epsilon arcs only upwards
+    (no cycles: the loaders reject those)."""
+    n = int(rng.integers(3, 9))
+    arcs = {}
+    for t in range(1, n + 1):
+        row = {}
+        for a in (A, B, E, SP, DOT, NL):
+            if rng.random() < 0.55:
+                row[a] = (int(rng.integers(1, n + 1)), bool(rng.random() < (0.6 if a in (SP, NL, E) else 0.1)))
+        if t < n and rng.random() < 0.45:
+            row[EPS] = (int(rng.integers(t + 1, n + 1)), False)
+        if rng.random() < 0.08:
+            row[UNKNOWN] = (int(rng.integers(1, n + 1)), False)
+        if rng.random() < 0.08:
+            row[IDENTITY] = (int(rng.integers(1, n + 1)), bool(rng.random() < 0.3))
+        arcs[t] = row
+    if not arcs[1]:
+        arcs[1][A] = (1, False)
+    return arcs
+
+
+def random_documents(rng, n=160):
+    alpha = ALPHABET + ("x\u00e4" if rng.random() < 0.5 else "")   # x, a-umlaut: not in the sigma (identity / unknown)
+    docs = [b"", b"a", b"\x04", b" ", b"a\x04a", b"a. b.\x04\n\na"]
+    for _ in range(n):
+        k = int(rng.integers(0, 90))
+        docs.append("".join(alpha[int(i)] for i in rng.integers(0, len(alpha), size=k)).encode())
+    long_ = [b"".join(docs[int(i)] for i in rng.integers(0, len(docs), size=30)) for _ in range(6)]
+    return docs + long_
