@@ -888,15 +888,13 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
   // The entry the next lookup is made with: the stream entry of the rune at p -- or, right after a backtrack,
   // the bare epsilon symbol: width 0, so that iteration consumes nothing and reads no rune (matrix.go:487-497).
   uint32_t e = row[p - wb7];
-  // `eot` of the reference survives a hard fail (matrix.go:499-552 does not clear it; the next rune does): if that rune
-  // was the document's last, the first successful epsilon step of the EOF drain fires the EOT's SentenceEnd / TextEnd
-  bool eot_stale = false;
 
   // Reader at EOF before a rune is read (matrix.go:650-668): epsilon arcs are taken as long as the state has one
   // (here, on the spot: one lookup each); then the remembered epsilon state is popped -- the walk goes on from
   // there with an epsilon iteration -- or the walk is over.
 #define DTK_EOF_DRAIN()                                                                                       \
   if (p >= len) {                                                                                             \
+    bool first_ = true;                                                                                       \
     while (t <= n_eps && !done) {                                                                             \
       const uint32_t x_ = tab[__umul24(t, stride) + epsilon];                                                 \
       const bool ov_ = __builtin_usub_overflow(budget, 1u, &budget);                                          \
@@ -915,8 +913,7 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
         F |= 1u;                                                                                              \
       }                                                                                                       \
       t = x_ & 0x7FFFu;                                                                                       \
-      if (eot_stale && !done) { /* matrix.go:593-605 behind the first successful step, see the hard-fail block */ \
-        eot_stale = false;                                                                                    \
+      if (eot_stale && first_ && !done) { /* matrix.go:593-605 behind the first successful step, see the hard-fail block */ \
         /* (a TextEnd behind a Token that ends at the same position: rows in call order, the exact pass) */   \
         if (MODE != MODE_START) sink.out_of_order();                                                          \
         if (MODE != MODE_START) sink.template eot<IS_MATRIX>(bs, p, (F & 1u) == 0u, (F & 8u) != 0);           \
@@ -929,13 +926,17 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
           }                                                                                                   \
         }                                                                                                     \
       }                                                                                                       \
+      first_ = false;                                                                                         \
       if (ov_) { st |= ST_STEP_LIMIT; done = true; }                                                          \
     }                                                                                                         \
     if (!done) {                                                                                              \
       if (eps_t != 0) { t = eps_t; p = eps_p; eps_t = 0; e = epsilon; } else done = true;                     \
     }                                                                                                         \
   }
-  DTK_EOF_DRAIN()
+  {
+    const bool eot_stale = false;
+    DTK_EOF_DRAIN()
+  }
   // The loop is rotated: the cell of the NEXT lookup is requested as soon as this one's cell says where the walk goes
   // (a dozen instructions behind its arrival), and everything else an iteration does -- events, token window, flags,
   // the epsilon slot -- runs while that request is under way.  In program order the whole iteration used to stand
@@ -986,7 +987,7 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
     // (a fused cell's rune is the first of its token unless the walk has backtracked to a slot BEHIND the token
     //  start -- bufft > buffc, the reference's own odd case: then its epsilon half neither flushes nor rewinds)
     const unsigned long long m_skip = __builtin_amdgcn_ballot_w64((x & 0x8000u) != 0u) &
-                                      ((m_comp & ~__builtin_amdgcn_ballot_w64(p < tp)) | (m_adv & __builtin_amdgcn_ballot_w64(p == tp)));
+                                      ((m_comp & __builtin_amdgcn_ballot_w64(p > tp)) | (m_adv & __builtin_amdgcn_ballot_w64(p == tp)));
     uint32_t en_n;
     {
       const uint32_t pn_n = p_n + ((e_n >> DTK_SYM_W_SHIFT) & 7u);
@@ -1044,6 +1045,11 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
         if (sentE) sink.template sentence<IS_MATRIX>(bs_old, p_old, (F_old & 8u) != 0);
       }
       if (flush && win > DTK_WINDOW && count_runes(s, bs_old, hi) > DTK_WINDOW) st |= ST_WINDOW_OVERFLOW;
+      // `eot` of the reference survives a hard fail (matrix.go:499-552 does not clear it; the next rune does): if that
+      // rune was the document's last, the first successful epsilon step of the EOF drain -- right below: the hard fail
+      // has dropped the epsilon slot, so the drain either takes that step or ends the walk -- fires the EOT's
+      // SentenceEnd / TextEnd
+      bool eot_stale = false;
       if (at_stop) {
         // the state right after the rewind at p_old: the target of the epsilon arc
         fin.p = p_old; fin.t = comp ? via : tgt; fin.aux = 0;
