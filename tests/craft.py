@@ -102,11 +102,11 @@ def documents(rng, n=400, max_len=60):
     return docs
 
 
-def random_automaton(rng):
+def random_automaton(rng, max_states=8):
     """A random arc table for matok_from / datok_from (scripts/fuzz_automata.py, tests/test_exact_and_replay.py):
     3-8 states, arcs on the six sigma symbols, now and then on `unknown` / `identity`; epsilon arcs only upwards
     (no cycles: the loaders reject those)."""
-    n = int(rng.integers(3, 9))
+    n = int(rng.integers(3, max_states + 1))
     arcs = {}
     for t in range(1, n + 1):
         row = {}
@@ -125,11 +125,13 @@ def random_automaton(rng):
     return arcs
 
 
-def random_documents(rng, n=160):
+def random_documents(rng, n=160, max_len=90, raw=()):
+    """`raw`: extra byte strings drawn like letters (invalid UTF-8, long runes)."""
     alpha = ALPHABET + ("x\u00e4" if rng.random() < 0.5 else "")   # x, a-umlaut: not in the sigma (identity / unknown)
+    letters = [c.encode() for c in alpha] + list(raw)
     docs = [b"", b"a", b"\x04", b" ", b"a\x04a", b"a. b.\x04\n\na"]
     for _ in range(n):
-        k = int(rng.integers(0, 90))
-        docs.append("".join(alpha[int(i)] for i in rng.integers(0, len(alpha), size=k)).encode())
+        k = int(rng.integers(0, max_len))
+        docs.append(b"".join(letters[int(i)] for i in rng.integers(0, len(letters), size=k)))
     long_ = [b"".join(docs[int(i)] for i in rng.integers(0, len(docs), size=30)) for _ in range(6)]
     return docs + long_
