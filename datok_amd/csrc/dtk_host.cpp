@@ -79,6 +79,7 @@ struct dtk_model {
   uint16_t *d_ascii = nullptr;
   uint32_t *d_runes = nullptr;
   uint16_t *d_syms = nullptr;
+  void *d_codes = nullptr;  // code_entry [256] u16, code_lt256 [256] u8, code_runes [n_runes] u8
   DtkTableDev tab{};
   DtkSigmaDev sig{};
 };
@@ -191,6 +192,43 @@ static int upload(dtk_model *m, const void *tab, size_t tab_bytes) {
     HIP_TRY(hipMemcpy(m->d_syms, syms_dev.data(), nr * sizeof(uint16_t), hipMemcpyHostToDevice));
   }
   m->device_bytes = tab_bytes + slack + 512 + nr * 6;
+  {
+    // The stream's code table (dtk_internal.h): every entry the symboliser can write for this model, numbered.
+    std::vector<uint16_t> entries;
+    bool fits = true;
+    auto code_of = [&](uint32_t e) -> uint8_t {
+      for (size_t i = 0; i < entries.size(); i++)
+        if (entries[i] == (uint16_t)e) return (uint8_t)i;
+      if (entries.size() >= DTK_SYM_CONT) { fits = false; return 0; }
+      entries.push_back((uint16_t)e);
+      return (uint8_t)(entries.size() - 1);
+    };
+    const uint32_t ident = m->identity < 0 ? 0u : colof(m->identity);
+    std::vector<uint8_t> bytes(256 + nr);
+    for (uint32_t i = 0; i < 256; i++)  // matrix.go:421-426; a rune of 128..255 takes two bytes
+      bytes[i] = code_of((ascii_dev[i] & DTK_SYM_MASK) | (i == DTK_EOT ? 1u << DTK_SYM_CLS_SHIFT : 0u) |
+                         ((i < 128 ? 1u : 2u) << DTK_SYM_W_SHIFT));
+    uint32_t fffd = (ident & DTK_SYM_MASK) | (3u << DTK_SYM_CLS_SHIFT);
+    for (size_t i = 0; i < nr; i++) {
+      const uint32_t r = m->sigma_runes[first + i], w = r < 0x800u ? 2u : (r < 0x10000u ? 3u : 4u);
+      const uint32_t e = (colof(m->sigma_syms[first + i]) & DTK_SYM_MASK) | (2u << DTK_SYM_CLS_SHIFT);
+      bytes[256 + i] = code_of(e | (w << DTK_SYM_W_SHIFT));
+      if (r == 0xFFFDu) fffd = e;
+    }
+    for (uint32_t w = 1; w <= 4; w++)
+      m->sig.code_ident[w] = code_of((ident & DTK_SYM_MASK) | (3u << DTK_SYM_CLS_SHIFT) | (w << DTK_SYM_W_SHIFT));
+    m->sig.code_ident[0] = DTK_SYM_CONT;
+    m->sig.code_fffd1 = code_of(fffd | (1u << DTK_SYM_W_SHIFT));  // an invalid byte decodes to U+FFFD, one byte wide
+    m->sig.n_codes = (fits && !getenv("DATOK_SYM16")) ? (uint32_t)entries.size() : 0u;
+    entries.resize(256, 0);  // (DTK_SYM_CONT and the unused codes: width 0)
+    HIP_TRY(hipMalloc(&m->d_codes, 512 + bytes.size()));
+    HIP_TRY(hipMemcpy(m->d_codes, entries.data(), 512, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy((char *)m->d_codes + 512, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+    m->sig.code_entry = (const uint16_t *)m->d_codes;
+    m->sig.code_lt256 = (const uint8_t *)m->d_codes + 512;
+    m->sig.code_runes = (const uint8_t *)m->d_codes + 768;
+    m->device_bytes += 512 + bytes.size();
+  }
   m->sig.ascii = m->d_ascii;
   m->sig.runes = m->d_runes;
   m->sig.syms = m->d_syms;
@@ -765,6 +803,7 @@ extern "C" void dtk_model_free(dtk_model *m) {
   if (m->d_ascii) (void)hipFree(m->d_ascii);
   if (m->d_runes) (void)hipFree(m->d_runes);
   if (m->d_syms) (void)hipFree(m->d_syms);
+  if (m->d_codes) (void)hipFree(m->d_codes);
   delete m;
 }
 
@@ -1172,9 +1211,15 @@ static int plan_lanes(dtk_batch *b) {
   return DTK_OK;
 }
 
+// the batch's symbol stream as its last run wrote it: codes + the model's table, or 16-bit entries
+static DtkSym sym_of(const dtk_batch *b) {
+  const dtk_model *m = b->last_model;
+  return DtkSym{b->d_sym, (m && m->sig.n_codes) ? m->sig.code_entry : nullptr};
+}
+
 static DtkWalkArgs walk_args(dtk_batch *b) {
   DtkWalkArgs w{};
-  w.sym = b->d_sym; w.doc_off = b->d_off; w.n_docs = b->n_docs;
+  w.sym = sym_of(b); w.doc_off = b->d_off; w.n_docs = b->n_docs;
   w.bits = b->d_bits; w.bit_words = b->bit_words; w.doc_tail = b->d_doc_tail; w.status = b->d_status;
   w.tok_cnt = b->d_tok_cnt; w.sent_cnt = b->d_sent_cnt; w.text_cnt = b->d_text_cnt;
   w.steps = (unsigned long long *)(b->d_totals + 16);
@@ -1423,7 +1468,7 @@ static int run_exact(dtk_batch *b) {
   }
   HIP_TRY(hipMemcpy(b->d_exact_ids, b->h_exact_ids.data(), (size_t)n * 4, hipMemcpyHostToDevice));
   DtkExactArgs X{};
-  X.sym = b->d_sym; X.text = b->d_text; X.doc_off = b->d_off; X.n = n; X.docs = b->d_exact_ids;
+  X.sym = sym_of(b); X.text = b->d_text; X.doc_off = b->d_off; X.n = n; X.docs = b->d_exact_ids;
   X.n_calls = b->d_exact_cnt; X.call_off = b->d_exact_off; X.status = b->d_status;
   X.flags = b->last_flags & DTK_NEWLINE_AFTER_EOT; X.step_factor = walk_args(b).step_factor;
   X.tok_off = b->d_tok_off; X.sent_off = b->d_sent_off; X.text_off = b->d_text_off;
@@ -1666,7 +1711,7 @@ static int render(dtk_batch *b, uint32_t bits) {
   R.rstart = b->d_rstart; R.rend = b->d_rend; R.sent = b->d_sent;
   R.bstart = b->d_bstart; R.bend = b->d_bend; R.sbefore = b->d_sbefore;
   R.ttok = b->d_ttok; R.tsent = b->d_tsent; R.ts_end = b->d_ts_end; R.doc_ns = b->d_doc_ns;
-  R.sym = b->n_invalid ? b->d_sym : nullptr;
+  R.sym = sym_of(b); if (!b->n_invalid) R.sym.base = nullptr;
   uint64_t *q = b->d_rws;
   R.A = q; q += nt + 1; R.P = q; q += nt + 1; R.Q = q; q += ns + 1;
   R.blkA = q; q += tt; R.blkP = q; q += tt; R.blkQ = q; q += st;

@@ -21,9 +21,30 @@
 #define DTK_SYM_CLS_SHIFT 14
 #define DTK_SYM_WIDTH(e) (((uint32_t)(e) >> DTK_SYM_W_SHIFT) & 7u)
 #define DTK_SYM_IS_START(e) (DTK_SYM_WIDTH(e) != 0u)
-// the lean walk's per-lane window of the symbol stream in LDS: entries, and u16 per row (72 B)
+// the walks' per-lane window of the symbol stream in LDS: entries, and u16 per row (72 B)
 #define DTK_WIN 32u
 #define DTK_WIN_ROW 36u
+// ---- the stream in memory: one BYTE per input byte where the model's entries fit a code table (DtkSigmaDev::n_codes:
+// the shipped models have 176 symbols and some 190 distinct entries), else the 16-bit entries themselves.  A code
+// is an index into `lut` (256 entries); DTK_SYM_CONT = no rune starts here.  Half the stream's traffic -- it was 44 %
+// of what a batch moves -- and a window of twice the positions in the same LDS (the lean walk keeps codes in its rows).
+#define DTK_SYM_CONT 0xFFu
+#ifndef DTK_WIN8
+#define DTK_WIN8 32u  // positions in a lean-walk row of codes (a multiple of 16; the row has 8 bytes more: 40 B)
+#endif
+struct DtkSym {
+  const void *base;     // uint8_t codes if lut, else uint16_t entries
+  const uint16_t *lut;  // [256] entry of a code (lut[DTK_SYM_CONT] has width 0), or null
+};
+#ifdef __HIP__
+__device__ __forceinline__ uint32_t dtk_sym_entry(const DtkSym &S, uint64_t i) {
+  return S.lut ? (uint32_t)S.lut[static_cast<const uint8_t *>(S.base)[i]] : (uint32_t)static_cast<const uint16_t *>(S.base)[i];
+}
+__device__ __forceinline__ bool dtk_sym_is_start(const DtkSym &S, uint64_t i) {
+  return S.lut ? static_cast<const uint8_t *>(S.base)[i] != DTK_SYM_CONT
+               : DTK_SYM_IS_START(static_cast<const uint16_t *>(S.base)[i]);
+}
+#endif
 
 // ---- walk output: event bitmaps over cursor positions.  Position p (0..len) of document d, which starts at
 // input byte `off`, is bit  G = off + d + p  (one position more than the document has bytes, so the ranges of
@@ -68,6 +89,13 @@ struct DtkSigmaDev {
   const uint16_t *syms;   // their symbols
   uint32_t n_runes;
   uint32_t identity;
+  // code table (n_codes != 0: the stream holds codes)
+  uint32_t n_codes;
+  const uint16_t *code_entry;  // [256] code -> entry
+  const uint8_t *code_lt256;   // [256] rune < 256 -> code (one byte wide below 128, two from 128 on)
+  const uint8_t *code_runes;   // [n_runes] sigma rune >= 256 in its UTF-8 width -> code
+  uint8_t code_ident[5];       // [w] a rune of w bytes that is not in the sigma (identity, ok = false)
+  uint8_t code_fffd1;          // an invalid byte (U+FFFD, one byte wide) if U+FFFD is in the sigma
 };
 
 enum { DTK_KIND_MATRIX = 0, DTK_KIND_DA = 1 };
@@ -157,7 +185,7 @@ struct DtkSpecArgs {
 };
 
 struct DtkWalkArgs {
-  const uint16_t *sym;      // symbol stream, one entry per input byte
+  struct DtkSym sym;        // symbol stream, one entry per input byte
   const uint64_t *doc_off;  // n_docs + 1
   uint32_t n_docs;
   uint32_t *bits;           // event bitmaps (EVB_KINDS x bit_words words), zero-filled
@@ -227,7 +255,7 @@ struct DtkSegIn {
 // listing their calls (dtk_call of datok_gpu.h) for closure replays.
 struct DtkCall { uint32_t kind; int32_t a; uint32_t b, c; };
 struct DtkExactArgs {
-  const uint16_t *sym;
+  struct DtkSym sym;
   const uint8_t *text;
   const uint64_t *doc_off;
   uint32_t n;               // documents to walk
@@ -259,7 +287,7 @@ struct DtkRenderArgs {
   const uint32_t *bstart, *bend, *sbefore;  // per token
   const uint32_t *ttok, *tsent, *ts_end;    // per text: tokens / sentence ints / SentenceEnd calls up to its TextEnd
   const uint32_t *doc_ns;                   // SentenceEnd calls per document
-  const uint16_t *sym;                      // symbol stream; non-null only if the batch has invalid UTF-8 bytes
+  struct DtkSym sym;                        // symbol stream; base non-null only if the batch has invalid UTF-8 bytes
   // workspace
   uint64_t *A, *P, *Q;           // exclusive scans: surface bytes, position digits (n_tok+1), sentence digits (n_sent+1)
   uint64_t *blkA, *blkP, *blkQ;  // per-tile sums
@@ -276,7 +304,7 @@ extern "C" {
 #endif
 // launchers (dtk_kernels.hip); stream is a hipStream_t
 int dtk_launch_symbolize(const uint8_t *text, const uint64_t *doc_off, uint32_t n_docs,
-                         uint64_t total, const struct DtkSigmaDev *sig, uint16_t *sym, int padded,
+                         uint64_t total, const struct DtkSigmaDev *sig, void *sym, int padded,
                          const uint32_t *blk_doc, unsigned long long *n_invalid, uint32_t *rs_bits,
                          uint32_t *ev_bits, uint32_t bit_words, void *acc, uint64_t acc_bytes, uint64_t epoch, void *stream);
 #define DTK_SYM_BLOCK_BYTES 4096u  // input bytes per symbolise block (blk_doc granularity)

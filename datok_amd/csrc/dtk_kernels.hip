@@ -97,11 +97,13 @@ __device__ __forceinline__ uint32_t doc_of(const uint64_t *__restrict__ doc_off,
 #define SYM_THREADS (WAVE * (SYM_BLOCK_BYTES / SYM_HALF))  // 256: four waves per 4 KiB block
 #define SYM_DOFF 256u  // document offsets of a block kept in LDS (documents of 16 bytes on average and longer)
 
-template <bool ALIGNED4>
+// SYM8: the stream holds one code per byte (DtkSigmaDev's code table) instead of the 16-bit entries; lut / lat then
+// hold codes too.
+template <bool ALIGNED4, bool SYM8>
 __global__ __launch_bounds__(SYM_THREADS) void k_symbolize(const uint8_t *__restrict__ text,
                                                     const uint64_t *__restrict__ doc_off,
                                                     uint32_t n_docs, uint64_t total, DtkSigmaDev sig,
-                                                    uint16_t *__restrict__ sym,
+                                                    void *__restrict__ sym_,
                                                     const uint32_t *__restrict__ blk_doc,
                                                     unsigned long long *__restrict__ n_invalid,
                                                     uint32_t *__restrict__ rs_bits,
@@ -118,11 +120,13 @@ __global__ __launch_bounds__(SYM_THREADS) void k_symbolize(const uint8_t *__rest
       else acc[i] = z;
     }
   }
+  uint16_t *__restrict__ sym = static_cast<uint16_t *>(sym_);
+  uint8_t *__restrict__ sym8 = static_cast<uint8_t *>(sym_);
   __shared__ uint32_t s_rs[SYM_BLOCK_BYTES / 32];  // bit i: byte i of the block starts a rune
   __shared__ uint16_t lut[128];       // symbol | class | width 1 for the runes < 128 (index = byte)
   __shared__ uint16_t lat[256];       // symbol | class for runes < 256 (heavy path, Latin-1)
   __shared__ uint32_t s_runes[SYM_SIG_LDS];   // sigma map (runes >= 256), if it fits
-  __shared__ uint16_t s_syms[SYM_SIG_LDS];
+  __shared__ uint16_t s_syms[SYM_SIG_LDS];  // (SYM8: their codes)
   __shared__ uint32_t s_txt[SYM_BLOCK_BYTES / 4 + 4];  // the block's bytes, one dword of halo either side
   __shared__ uint16_t s_qs[SYM_BLOCK_BYTES / SYM_HALF][SYM_HALF];  // per wave: positions (offset in the block) of the bytes >= 0x80 of its quarter
   __shared__ uint64_t s_doff[SYM_DOFF];  // the offsets of the documents of this block (if they are that few)
@@ -132,10 +136,16 @@ __global__ __launch_bounds__(SYM_THREADS) void k_symbolize(const uint8_t *__rest
   for (uint32_t i = tid; i < SYM_BLOCK_BYTES / 32; i += SYM_THREADS) s_rs[i] = 0;
   for (uint32_t i = tid; i < 256u; i += SYM_THREADS) {
     // matrix.go:421-426: runes < 256 go through sigmaASCII; rune 4 is EOT
-    const uint32_t e = (sig.ascii[i] & DTK_SYM_MASK) | (i == DTK_EOT ? (1u << DTK_SYM_CLS_SHIFT) : 0u);
-    lat[i] = (uint16_t)e;
-    if (i < 128u) lut[i] = (uint16_t)(e | (1u << DTK_SYM_W_SHIFT));
-    if (sig_lds && i < sig.n_runes) { s_runes[i] = sig.runes[i]; s_syms[i] = sig.syms[i]; }
+    if (SYM8) {
+      lat[i] = sig.code_lt256[i];
+      if (i < 128u) lut[i] = sig.code_lt256[i];
+      if (sig_lds && i < sig.n_runes) { s_runes[i] = sig.runes[i]; s_syms[i] = sig.code_runes[i]; }
+    } else {
+      const uint32_t e = (sig.ascii[i] & DTK_SYM_MASK) | (i == DTK_EOT ? (1u << DTK_SYM_CLS_SHIFT) : 0u);
+      lat[i] = (uint16_t)e;
+      if (i < 128u) lut[i] = (uint16_t)(e | (1u << DTK_SYM_W_SHIFT));
+      if (sig_lds && i < sig.n_runes) { s_runes[i] = sig.runes[i]; s_syms[i] = sig.syms[i]; }
+    }
   }
   const uint64_t block_start = (uint64_t)blockIdx.x * SYM_BLOCK_BYTES;
   const uint32_t n_here = (uint32_t)min((uint64_t)SYM_BLOCK_BYTES, total - block_start);
@@ -183,7 +193,8 @@ __global__ __launch_bounds__(SYM_THREADS) void k_symbolize(const uint8_t *__rest
 #pragma unroll
       for (uint32_t k = 0; k < EVB_KINDS; k++) ev_bits[(size_t)k * bit_words + w] = 0u;
   }
-  const bool sym16 = ((reinterpret_cast<uintptr_t>(sym) + 2ull * block_start) & 15u) == 0;
+  // (the light path's vector stores: 8 entries = 16 bytes, or 8 codes = 8 bytes)
+  const bool sym16 = ((reinterpret_cast<uintptr_t>(sym_) + (SYM8 ? 1ull : 2ull) * block_start) & (SYM8 ? 7u : 15u)) == 0;
 
   // (the four quarters used to be one wave's four rounds: a chain of load -> light -> wait for the stores -> heavy,
   //  four times over, with four waves per SIMD to hide it; now the rounds are four waves)
@@ -204,11 +215,17 @@ __global__ __launch_bounds__(SYM_THREADS) void k_symbolize(const uint8_t *__rest
       uint32_t left = 8u;
       if (!FULL) left = i0 < n_here ? (n_here - i0 >= 8u ? 8u : n_here - i0) : 0u;
       if (FULL || (left == 8u && sym16)) {
-        *reinterpret_cast<uint4 *>(sym + block_start + i0) =
-            make_uint4(e0 | (e1 << 16), e2 | (e3 << 16), e4 | (e5 << 16), e6 | (e7 << 16));
+        if (SYM8)
+          *reinterpret_cast<uint2 *>(sym8 + block_start + i0) =
+              make_uint2(e0 | (e1 << 8) | (e2 << 16) | (e3 << 24), e4 | (e5 << 8) | (e6 << 16) | (e7 << 24));
+        else
+          *reinterpret_cast<uint4 *>(sym + block_start + i0) =
+              make_uint4(e0 | (e1 << 16), e2 | (e3 << 16), e4 | (e5 << 16), e6 | (e7 << 16));
       } else {
         const uint32_t o[8] = {e0, e1, e2, e3, e4, e5, e6, e7};
-        for (uint32_t j = 0; j < left; j++) sym[block_start + i0 + j] = (uint16_t)o[j];
+        for (uint32_t j = 0; j < left; j++) {
+          if (SYM8) sym8[block_start + i0 + j] = (uint8_t)o[j]; else sym[block_start + i0 + j] = (uint16_t)o[j];
+        }
       }
       // one bit per byte: bytes < 0x80 start a rune (the others are decided one by one below)
       auto nib = [](uint32_t x) { return ((x >> 7) & 1u) | ((x >> 14) & 2u) | ((x >> 21) & 4u) | ((x >> 28) & 8u); };
@@ -292,24 +309,30 @@ __global__ __launch_bounds__(SYM_THREADS) void k_symbolize(const uint8_t *__rest
         const uint32_t r3 = ((b0 & 0x0Fu) << 12) | ((b1 & 0x3Fu) << 6) | (b2 & 0x3Fu);
         const uint32_t r4 = ((b0 & 0x07u) << 18) | ((b1 & 0x3Fu) << 12) | ((b2 & 0x3Fu) << 6) | (b3 & 0x3Fu);
         const uint32_t rune = wd == 1 ? 0xFFFDu : (wd == 2 ? r2 : (wd == 3 ? r3 : r4));
-        uint32_t a_cls;
+        uint32_t a_cls;  // (SYM8: the code of the rune in the width it has here)
         if (rune < 256u) {
-          a_cls = lat[rune];
+          a_cls = lat[rune];  // (two bytes wide: 128..255)
         } else {  // matrix.go:427-435: a, ok = sigma[char]; !ok -> identity
           int l = 0, h = (int)sig.n_runes - 1;
           a_cls = (sig.identity & DTK_SYM_MASK) | (3u << DTK_SYM_CLS_SHIFT);
+          if (SYM8)  // (selects: a per-lane index into the kernel argument would go through scratch memory)
+            a_cls = wd == 1u ? sig.code_ident[1] : (wd == 2u ? sig.code_ident[2] : (wd == 3u ? sig.code_ident[3] : sig.code_ident[4]));
           while (l <= h) {
             const int m = (l + h) >> 1;
             const uint32_t r = sig_lds ? s_runes[m] : sig.runes[m];
             if (r == rune) {
-              a_cls = ((sig_lds ? (uint32_t)s_syms[m] : (uint32_t)sig.syms[m]) & DTK_SYM_MASK) |
-                      (2u << DTK_SYM_CLS_SHIFT);
+              if (SYM8)  // (U+FFFD itself in the sigma: three bytes wide as a rune, one as an invalid byte)
+                a_cls = wd == 1u ? (uint32_t)sig.code_fffd1 : (sig_lds ? (uint32_t)s_syms[m] : (uint32_t)sig.code_runes[m]);
+              else
+                a_cls = ((sig_lds ? (uint32_t)s_syms[m] : (uint32_t)sig.syms[m]) & DTK_SYM_MASK) |
+                        (2u << DTK_SYM_CLS_SHIFT);
               break;
             }
             if (r < rune) l = m + 1; else h = m - 1;
           }
         }
-        sym[g] = (uint16_t)(a_cls | (start ? wd << DTK_SYM_W_SHIFT : 0u));
+        if (SYM8) sym8[g] = (uint8_t)(start ? a_cls : DTK_SYM_CONT);
+        else sym[g] = (uint16_t)(a_cls | (start ? wd << DTK_SYM_W_SHIFT : 0u));
         if (start) atomicOr(&s_rs[pos >> 5], 1u << (pos & 31u));
         // a byte that decodes to U+FFFD with width 1 prints as three bytes (the renderer's slow path)
         bad = start && wd == 1u;
@@ -608,23 +631,58 @@ enum { MODE_DOC = 0,    // whole document from the initial state, all events
 
 // Runes in [from, to): only needed when a window may have outgrown the
 // reference's 1024-rune buffer (matrix.go:365), i.e. when it spans > 1024 bytes.
-__device__ __noinline__ uint32_t count_runes(const uint16_t *__restrict__ s, uint32_t from, uint32_t to) {
+struct DtkSymAt { DtkSym S; uint64_t off; };  // a document's stretch of the stream
+__device__ __noinline__ uint32_t count_runes(const DtkSymAt &s, uint32_t from, uint32_t to) {
   uint32_t n = 0;
-  for (uint32_t i = from; i < to; i++) n += DTK_SYM_IS_START(s[i]) ? 1u : 0u;
+  for (uint32_t i = from; i < to; i++) n += dtk_sym_is_start(s.S, s.off + i) ? 1u : 0u;
   return n;
 }
 
 // window of the symbol stream in LDS (see walk_fused)
 typedef uint2 __attribute__((may_alias)) dtk_u2a;
 typedef uint16_t __attribute__((may_alias)) dtk_u16a;
-__device__ __forceinline__ void win_fill(dtk_u16a *row, const uint16_t *__restrict__ aligned, uint32_t wbase) {
-  const uint4 *__restrict__ g = reinterpret_cast<const uint4 *>(aligned + wbase);
+typedef uint8_t __attribute__((may_alias)) dtk_u8a;
+// (the general loop keeps entries in its rows: from a stream of codes they are translated on the way in -- 32 table
+//  reads per refill, cached; the loop itself does not know the difference.  `at` = stream index of the row's entry 0,
+//  a multiple of 8)
+__device__ __forceinline__ void win_fill(dtk_u16a *row, const DtkSym &S, uint64_t at) {
+  if (S.lut) {
+    const uint2 *__restrict__ g = reinterpret_cast<const uint2 *>(static_cast<const uint8_t *>(S.base) + at);
+    uint2 c[DTK_WIN / 8u];
+#pragma unroll
+    for (uint32_t i = 0; i < DTK_WIN / 8u; i++) c[i] = g[i];
+    dtk_u2a *r = reinterpret_cast<dtk_u2a *>(row);
+#pragma unroll
+    for (uint32_t i = 0; i < DTK_WIN / 8u; i++) {
+      const uint32_t lo = c[i].x, hi = c[i].y;
+      r[2 * i] = make_uint2((uint32_t)S.lut[lo & 255u] | ((uint32_t)S.lut[(lo >> 8) & 255u] << 16),
+                            (uint32_t)S.lut[(lo >> 16) & 255u] | ((uint32_t)S.lut[lo >> 24] << 16));
+      r[2 * i + 1] = make_uint2((uint32_t)S.lut[hi & 255u] | ((uint32_t)S.lut[(hi >> 8) & 255u] << 16),
+                                (uint32_t)S.lut[(hi >> 16) & 255u] | ((uint32_t)S.lut[hi >> 24] << 16));
+    }
+    return;
+  }
+  const uint4 *__restrict__ g = reinterpret_cast<const uint4 *>(static_cast<const uint16_t *>(S.base) + at);
   uint4 v[DTK_WIN / 8u];
 #pragma unroll
   for (uint32_t i = 0; i < DTK_WIN / 8u; i++) v[i] = g[i];  // all loads before the first LDS write
   dtk_u2a *r = reinterpret_cast<dtk_u2a *>(row);
 #pragma unroll
   for (uint32_t i = 0; i < DTK_WIN / 8u; i++) {
+    r[2 * i] = make_uint2(v[i].x, v[i].y);
+    r[2 * i + 1] = make_uint2(v[i].z, v[i].w);
+  }
+}
+
+// the lean loop's row: DTK_WIN8 codes
+__device__ __forceinline__ void win_fill8(dtk_u8a *row, const uint8_t *__restrict__ from) {
+  const uint4 *__restrict__ g = reinterpret_cast<const uint4 *>(from);
+  uint4 v[DTK_WIN8 / 16u];
+#pragma unroll
+  for (uint32_t i = 0; i < DTK_WIN8 / 16u; i++) v[i] = g[i];  // all loads before the first LDS write
+  dtk_u2a *r = reinterpret_cast<dtk_u2a *>(row);
+#pragma unroll
+  for (uint32_t i = 0; i < DTK_WIN8 / 16u; i++) {
     r[2 * i] = make_uint2(v[i].x, v[i].y);
     r[2 * i + 1] = make_uint2(v[i].z, v[i].w);
   }
@@ -639,7 +697,7 @@ __device__ __forceinline__ void win_fill(dtk_u16a *row, const uint16_t *__restri
 // symbol stream (read through the lane's window in LDS) replaces the rune -> symbol lookups
 // of matrix.go:421-435.
 template <typename TRANS, bool IS_MATRIX, int MODE, typename SINK = EventSink>
-__device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__restrict__ sym_base,
+__device__ __forceinline__ void walk_lane(const TRANS &tr, const DtkSym &sym,
                                           uint64_t off, uint32_t len, DtkLaneState init, uint32_t stop_pos,
                                           SINK &sink, uint32_t epsilon, uint32_t unknown,
                                           uint32_t identity, uint32_t cap, DtkLaneState &fin,
@@ -647,8 +705,8 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
   // the lane's window of the symbol stream in LDS: entries (pos + o7) in [wbase, wbase + DTK_WIN)
   dtk_u16a *row = reinterpret_cast<dtk_u16a *>(win_row);
   const uint32_t o7 = (uint32_t)(off & 7u);
-  const uint16_t *__restrict__ aligned = sym_base + (off - o7);
-  const uint16_t *__restrict__ s = sym_base + off;
+  const uint64_t aligned = off - o7;
+  const DtkSymAt s{sym, off};
 
   uint32_t a = 0, t0 = 0, aux0 = 0;
   uint32_t t = init.t, aux = init.aux;  // matrix.go:351 `t := uint32(1)`
@@ -672,7 +730,7 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
   bool has_tok = init.p > 0 && !text_end;  // pos[] of the current text is not empty
 
   uint32_t wbase = (init.p + o7) & ~7u;
-  win_fill(row, aligned, wbase);
+  win_fill(row, sym, aligned + wbase);
 
   // One table lookup per iteration (the reference's loop body, matrix.go:384-635),
   // written as predicates + selects so that the 64 lanes of a wave, which are all
@@ -695,7 +753,7 @@ __device__ __forceinline__ void walk_lane(const TRANS &tr, const uint16_t *__res
     // a lane that needs a rune outside its window: all lanes of the wave re-base theirs
     if (__builtin_amdgcn_ballot_w64(newchar && (p + o7 - wbase) >= DTK_WIN) != 0ull) {
       wbase = (p + o7) & ~7u;
-      win_fill(row, aligned, wbase);
+      win_fill(row, sym, aligned + wbase);
     }
     if (newchar) {
       const uint32_t e = row[p + o7 - wbase];
@@ -860,11 +918,12 @@ extern "C" int dtk_probe_read(unsigned long long *out, int reset) {
 #endif
 
 template <int MODE, bool FIRST = false, bool IS_MATRIX = true>
-__device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uint16_t *__restrict__ sym_base,
+__device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const DtkSym &sym,
                                            uint64_t off, uint32_t len, DtkLaneState init, uint32_t stop_pos,
                                            EventSink &sink, uint32_t epsilon, uint32_t cap, DtkLaneState &fin,
-                                           uint32_t &st_out, uint32_t &steps_out, uint16_t *win_row) {
-  const uint16_t *__restrict__ s = sym_base + off;
+                                           uint32_t &st_out, uint32_t &steps_out, uint16_t *win_row,
+                                           const uint16_t *lut) {
+  const DtkSymAt s{sym, off};
   const uint32_t *__restrict__ tab = tr.tab;
   const uint32_t stride = tr.stride, n_eps = tr.n_eps;
   uint32_t t = init.t;
@@ -879,15 +938,18 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
   uint32_t budget = cap;  // lookups left; the one that finds none left sets ST_STEP_LIMIT
   fin.p = 0xFFFFFFFFu; fin.t = 0; fin.aux = 0; fin.flags = 0;  // p stays "ran to EOF" unless the lane stops
   bool done = false;
-  // the lane's window of the symbol stream: entry of position q at row[q - wb7], q - wb7 in [0, DTK_WIN)
-  dtk_u16a *row = reinterpret_cast<dtk_u16a *>(win_row);
-  const uint32_t o7 = (uint32_t)(off & 7u);
-  const uint16_t *__restrict__ aligned = sym_base + (off - o7);
-  uint32_t wb7 = ((p + o7) & ~7u) - o7;
-  win_fill(row, aligned, wb7 + o7);
+  // the lane's window of the symbol stream: the CODE of position q at row[q - wb7], q - wb7 in [0, DTK_WIN8); its
+  // entry is lut[code] (the model's code table, in LDS)
+  dtk_u8a *row = reinterpret_cast<dtk_u8a *>(win_row);
+  const uint32_t o7 = (uint32_t)(off & 15u);  // (windows start at multiples of 16 codes: 16-byte loads)
+  const uint8_t *__restrict__ aligned = static_cast<const uint8_t *>(sym.base) + (off - o7);
+#define DTK_ENTRY(q_) ((uint32_t)lut[row[(q_) - wb7]])
+#define DTK_REFILL(q_) { wb7 = (((q_) + o7) & ~15u) - o7; win_fill8(row, aligned + (wb7 + o7)); }
+  uint32_t wb7;
+  DTK_REFILL(p)
   // The entry the next lookup is made with: the stream entry of the rune at p -- or, right after a backtrack,
   // the bare epsilon symbol: width 0, so that iteration consumes nothing and reads no rune (matrix.go:487-497).
-  uint32_t e = row[p - wb7];
+  uint32_t e = DTK_ENTRY(p);
 
   // Reader at EOF before a rune is read (matrix.go:650-668): epsilon arcs are taken as long as the state has one
   // (here, on the spot: one lookup each); then the remembered epsilon state is popped -- the walk goes on from
@@ -951,8 +1013,8 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
   if (!done) {
     x = DTK_TAB(t, e);
     const uint32_t pn0 = p + ((e >> DTK_SYM_W_SHIFT) & 7u);
-    if (pn0 - wb7 >= DTK_WIN) { wb7 = ((pn0 + o7) & ~7u) - o7; win_fill(row, aligned, wb7 + o7); }
-    en = row[pn0 - wb7];
+    if (pn0 - wb7 >= DTK_WIN8) DTK_REFILL(pn0)
+    en = DTK_ENTRY(pn0);
   }
 #ifdef DTK_PROBE
   unsigned long long pr_wait = 0, pr_t0 = clock64(), pr_n = 0;
@@ -988,16 +1050,15 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
     //  start -- bufft > buffc, the reference's own odd case: then its epsilon half neither flushes nor rewinds)
     const unsigned long long m_skip = __builtin_amdgcn_ballot_w64((x & 0x8000u) != 0u) &
                                       ((m_comp & __builtin_amdgcn_ballot_w64(p > tp)) | (m_adv & __builtin_amdgcn_ballot_w64(p == tp)));
-    uint32_t en_n;
+    uint32_t code_n;  // (its entry is looked up at the end of the iteration: the code has arrived by then)
     {
       const uint32_t pn_n = p_n + ((e_n >> DTK_SYM_W_SHIFT) & 7u);
       uint32_t iw = pn_n - wb7;
-      if (__builtin_amdgcn_ballot_w64(iw >= DTK_WIN) != 0ull) {  // also a backtrack to before the window
-        wb7 = ((pn_n + o7) & ~7u) - o7;
-        win_fill(row, aligned, wb7 + o7);
+      if (__builtin_amdgcn_ballot_w64(iw >= DTK_WIN8) != 0ull) {  // also a backtrack to before the window
+        DTK_REFILL(pn_n)
         iw = pn_n - wb7;
       }
-      en_n = row[iw];
+      code_n = row[iw];
     }
     // ---- this iteration's bookkeeping, under the request
     hi = max(hi, pn);                                   // matrix.go:388-408
@@ -1031,7 +1092,7 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
     eps_t = he2 ? via : ((backtrack || epsE) ? 0u : eps_t);
     eps_p = he2 ? p_old : eps_p;
     const uint32_t e_cur = e, e_next = en;
-    p = p_n; t = t_n; e = e_n; x = x_n; en = en_n;
+    p = p_n; t = t_n; e = e_n; x = x_n; en = lut[code_n];
     // everything that happens less than once per token: hard fail, EOT, the first rewind at or behind the end of
     // the chunk (a fused cell's too: the lane then ends BEFORE the cell's rune), the window limit, the lookup cap,
     // the reader at EOF
@@ -1101,8 +1162,8 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
       if (!done) {  // ask again: state, position or entry may have changed
         x = DTK_TAB(t, e);
         const uint32_t pn2 = p + ((e >> DTK_SYM_W_SHIFT) & 7u);
-        if (pn2 - wb7 >= DTK_WIN) { wb7 = ((pn2 + o7) & ~7u) - o7; win_fill(row, aligned, wb7 + o7); }
-        en = row[pn2 - wb7];
+        if (pn2 - wb7 >= DTK_WIN8) DTK_REFILL(pn2)
+        en = DTK_ENTRY(pn2);
       }
     }
 #ifdef DTK_PROBE
@@ -1115,6 +1176,8 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
 #endif
   }
 #undef DTK_TAB
+#undef DTK_ENTRY
+#undef DTK_REFILL
 #ifdef DTK_PROBE
   {
     // (the wave's clock: every lane reads the same counter; the wave leaves the loop with its last lane)
@@ -1150,15 +1213,15 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const uin
 
 // the lean walk: fused cells and no arc on `unknown` (MatrixLeanTrans, picked by the launcher)
 template <typename TRANS, bool IS_MATRIX, int MODE, bool FIRST = false>
-__device__ __forceinline__ void walk_any(const TRANS &tr, const uint16_t *__restrict__ sym_base, uint64_t off,
+__device__ __forceinline__ void walk_any(const TRANS &tr, const DtkSym &sym, uint64_t off,
                                          uint32_t len, DtkLaneState init, uint32_t stop_pos, EventSink &sink,
                                          uint32_t epsilon, uint32_t unknown, uint32_t identity, uint32_t cap,
                                          DtkLaneState &fin, uint32_t &st_out, uint32_t &steps_out,
-                                         uint16_t *win_row) {
+                                         uint16_t *win_row, const uint16_t *lut) {
   if constexpr (TRANS::LEAN)
-    walk_fused<MODE, FIRST, IS_MATRIX>(tr, sym_base, off, len, init, stop_pos, sink, epsilon, cap, fin, st_out, steps_out, win_row);
+    walk_fused<MODE, FIRST, IS_MATRIX>(tr, sym, off, len, init, stop_pos, sink, epsilon, cap, fin, st_out, steps_out, win_row, lut);
   else
-    walk_lane<TRANS, IS_MATRIX, MODE>(tr, sym_base, off, len, init, stop_pos, sink, epsilon, unknown, identity, cap,
+    walk_lane<TRANS, IS_MATRIX, MODE>(tr, sym, off, len, init, stop_pos, sink, epsilon, unknown, identity, cap,
                                       fin, st_out, steps_out, win_row);
 }
 
@@ -1183,7 +1246,7 @@ __device__ __forceinline__ void add_steps(unsigned long long *counter, uint32_t 
 // kind 1 SentenceEnd(a); kind 2 TextEnd(a) -- the int arguments as upstream: matrix.go:575,597,600,684,691
 // pass buffc, datok.go:1015,1026,1119,1127 pass 0 and only :1023 buffc).
 struct ExactSink {
-  const uint16_t *s;   // the document's symbol stream (bit 15: rune start)
+  DtkSymAt s;          // the document's stretch of the symbol stream (rune starts)
   const uint8_t *txt;  // the document's bytes
   bool nl_rule, write;
   DtkCall *log;
@@ -1267,6 +1330,17 @@ struct ExactSink {
   __device__ __forceinline__ void out_of_order() {}  // (call order is what this sink records)
 };
 
+// the lanes' windows of the symbol stream and, for the lean loop, the model's code table (one wave per block)
+#define DTK_WINDOWS(TRANS, SYM)                                                                       \
+  constexpr uint32_t WIN_ROW_ = TRANS::LEAN ? (DTK_WIN8 + 8u) / 2u : DTK_WIN_ROW;                     \
+  __shared__ uint16_t s_win[WAVE * WIN_ROW_];                                                         \
+  __shared__ uint16_t s_lut[TRANS::LEAN ? 256 : 1];                                                   \
+  uint16_t *win_row = s_win + threadIdx.x * WIN_ROW_;                                                 \
+  if constexpr (TRANS::LEAN) {                                                                        \
+    for (uint32_t i_ = threadIdx.x; i_ < 256u; i_ += WAVE) s_lut[i_] = (SYM).lut[i_];                 \
+    __syncthreads();                                                                                  \
+  }
+
 template <typename TRANS, bool IS_MATRIX>
 __global__ __launch_bounds__(WAVE) void k_exact_doc(TRANS tr, DtkExactArgs X, uint32_t epsilon, uint32_t unknown,
                                                     uint32_t identity) {
@@ -1278,7 +1352,7 @@ __global__ __launch_bounds__(WAVE) void k_exact_doc(TRANS tr, DtkExactArgs X, ui
   const uint64_t off = X.doc_off[d];
   const uint32_t len = (uint32_t)(X.doc_off[d + 1] - off);
   ExactSink sink;
-  sink.s = X.sym + off; sink.txt = X.text + off;
+  sink.s = DtkSymAt{X.sym, off}; sink.txt = X.text + off;
   sink.nl_rule = (X.flags & 16u) != 0; sink.write = X.pass != 0;
   sink.log = X.pass ? X.calls + X.call_off[i] : nullptr;
   const uint64_t t0 = X.tok_off[d], s0 = X.sent_off[d], x0 = X.text_off[d];
@@ -1306,8 +1380,7 @@ __global__ __launch_bounds__(WAVE) void k_exact_doc(TRANS tr, DtkExactArgs X, ui
 template <typename TRANS, bool IS_MATRIX>
 __global__ __launch_bounds__(WAVE) void k_walk_doc(TRANS tr, DtkWalkArgs A, uint32_t epsilon,
                                                    uint32_t unknown, uint32_t identity) {
-  __shared__ uint16_t s_win[WAVE * DTK_WIN_ROW];
-  uint16_t *win_row = s_win + threadIdx.x * DTK_WIN_ROW;
+  DTK_WINDOWS(TRANS, A.sym)
   const uint32_t d = blockIdx.x * WAVE + threadIdx.x;
   uint32_t steps = 0;
   if (d < A.n_docs) {
@@ -1318,7 +1391,7 @@ __global__ __launch_bounds__(WAVE) void k_walk_doc(TRANS tr, DtkWalkArgs A, uint
     DtkLaneState init{0u, tr.start_state(), tr.start_aux(), 0u}, fin;
     uint32_t st;
     walk_any<TRANS, IS_MATRIX, MODE_DOC>(tr, A.sym, off, len, init, 0u, sink, epsilon, unknown,
-                                          identity, step_cap(A.step_factor, len), fin, st, steps, win_row);
+                                          identity, step_cap(A.step_factor, len), fin, st, steps, win_row, s_lut);
     A.status[d] = st | sink.st;
     A.tok_cnt[d] = sink.c_tok; A.sent_cnt[d] = sink.c_sent; A.text_cnt[d] = sink.c_text;
   }
@@ -1357,8 +1430,7 @@ template <typename TRANS, bool IS_MATRIX>
 __device__ __forceinline__ DtkLaneState start_record(const TRANS &tr, const DtkWalkArgs &A, const DtkSpecArgs &S,
                                                      uint32_t k, uint64_t off, uint32_t len, uint32_t epsilon,
                                                      uint32_t unknown, uint32_t identity, uint16_t *win_row,
-                                                     uint32_t &steps) {
-  const uint16_t *__restrict__ s = A.sym + off;
+                                                     const uint16_t *s_lut, uint32_t &steps) {
   DtkLaneState rec{0u, tr.start_state(), tr.start_aux(), 0u};
   if (k > 0) {
     const uint32_t kc = k * S.chunk;
@@ -1447,14 +1519,14 @@ __device__ __forceinline__ DtkLaneState start_record(const TRANS &tr, const DtkW
     sink.g = nullptr; sink.lds = (dtk_lds_u32 *)nullptr; sink.tailw = nullptr; sink.lw = 0; sink.lo = sink.hi = 0;
     uint32_t st;
     if (sp > 0) {
-      while (sp < len && !DTK_SYM_IS_START(s[sp])) sp++;
+      while (sp < len && !dtk_sym_is_start(A.sym, off + sp)) sp++;
       DtkLaneState init{sp, tr.start_state(), tr.start_aux(), 0u};
       walk_any<TRANS, IS_MATRIX, MODE_START>(tr, A.sym, off, len, init, kc, sink, epsilon, unknown,
-                                              identity, step_cap(A.step_factor, len), rec, st, steps, win_row);
+                                              identity, step_cap(A.step_factor, len), rec, st, steps, win_row, s_lut);
     } else {
       // sp == 0: the walk from the true initial state; its first sync point at/after kc
       walk_any<TRANS, IS_MATRIX, MODE_START>(tr, A.sym, off, len, rec, kc, sink, epsilon, unknown,
-                                              identity, step_cap(A.step_factor, len), rec, st, steps, win_row);
+                                              identity, step_cap(A.step_factor, len), rec, st, steps, win_row, s_lut);
     }
   }
   return rec;
@@ -1464,8 +1536,7 @@ template <typename TRANS, bool IS_MATRIX>
 __global__ __launch_bounds__(WAVE) void k_spec_start(TRANS tr, DtkWalkArgs A, DtkSpecArgs S,
                                                      uint32_t epsilon, uint32_t unknown,
                                                      uint32_t identity) {
-  __shared__ uint16_t s_win[WAVE * DTK_WIN_ROW];
-  uint16_t *win_row = s_win + threadIdx.x * DTK_WIN_ROW;
+  DTK_WINDOWS(TRANS, A.sym)
   const uint32_t L = blockIdx.x * WAVE + threadIdx.x;
   uint32_t steps = 0;
   if (L < S.n_lanes) {
@@ -1473,7 +1544,7 @@ __global__ __launch_bounds__(WAVE) void k_spec_start(TRANS tr, DtkWalkArgs A, Dt
     const uint32_t k = L - S.chunk_off[d];
     const uint64_t off = A.doc_off[d];
     const uint32_t len = (uint32_t)(A.doc_off[d + 1] - off);
-    S.lane_start[L] = start_record<TRANS, IS_MATRIX>(tr, A, S, k, off, len, epsilon, unknown, identity, win_row, steps);
+    S.lane_start[L] = start_record<TRANS, IS_MATRIX>(tr, A, S, k, off, len, epsilon, unknown, identity, win_row, s_lut, steps);
   }
   add_steps(A.steps, steps);
 }
@@ -1488,8 +1559,7 @@ template <typename TRANS, bool IS_MATRIX>
 __global__ __launch_bounds__(WAVE) void k_spec_both(TRANS tr, DtkWalkArgs A, DtkSpecArgs S,
                                                     uint32_t epsilon, uint32_t unknown,
                                                     uint32_t identity) {
-  __shared__ uint16_t s_win[WAVE * DTK_WIN_ROW];
-  uint16_t *win_row = s_win + threadIdx.x * DTK_WIN_ROW;
+  DTK_WINDOWS(TRANS, A.sym)
   uint32_t *lds_bits = S.lds_words ? s_dyn_bits : nullptr;
 #ifdef DTK_PROBE
   const unsigned long long pt0 = clock64();
@@ -1506,7 +1576,7 @@ __global__ __launch_bounds__(WAVE) void k_spec_both(TRANS tr, DtkWalkArgs A, Dtk
     const uint64_t off = A.doc_off[d];
     const uint32_t len = (uint32_t)(A.doc_off[d + 1] - off);
     const DtkLaneState rec =
-        start_record<TRANS, IS_MATRIX>(tr, A, S, k, off, len, epsilon, unknown, identity, win_row, steps);
+        start_record<TRANS, IS_MATRIX>(tr, A, S, k, off, len, epsilon, unknown, identity, win_row, s_lut, steps);
 #ifdef DTK_PROBE
     pt1 = clock64();
 #endif
@@ -1524,7 +1594,7 @@ __global__ __launch_bounds__(WAVE) void k_spec_both(TRANS tr, DtkWalkArgs A, Dtk
       sink.init(A, off, d, rec.p, 0xFFFFFFFFu, lds_bits, S.lds_words, w0);
       uint32_t st = 0, steps2 = 0;
       walk_any<TRANS, IS_MATRIX, MODE_CHUNK, true>(tr, A.sym, off, len, rec, stop, sink, epsilon, unknown,
-                                                    identity, step_cap(A.step_factor, len), fin, st, steps2, win_row);
+                                                    identity, step_cap(A.step_factor, len), fin, st, steps2, win_row, s_lut);
       steps += steps2;
       if (sink.dropped) fin.flags |= LANE_F_DROPPED;
       cnt.tok = sink.c_tok; cnt.sent = sink.c_sent; cnt.text = sink.c_text; cnt.status = st | sink.st;
@@ -1594,8 +1664,7 @@ template <typename TRANS, bool IS_MATRIX>
 __global__ __launch_bounds__(WAVE) void k_spec_walk(TRANS tr, DtkWalkArgs A, DtkSpecArgs S,
                                                     uint32_t epsilon, uint32_t unknown,
                                                     uint32_t identity) {
-  __shared__ uint16_t s_win[WAVE * DTK_WIN_ROW];
-  uint16_t *win_row = s_win + threadIdx.x * DTK_WIN_ROW;
+  DTK_WINDOWS(TRANS, A.sym)
   if (S.go && *S.go == 0u) return;
   uint32_t *lds_bits = S.lds_words ? s_dyn_bits : nullptr;
   const uint32_t L = blockIdx.x * WAVE + threadIdx.x;
@@ -1622,7 +1691,7 @@ __global__ __launch_bounds__(WAVE) void k_spec_walk(TRANS tr, DtkWalkArgs A, Dtk
         sink.init(A, off, d, init.p, pl.wend, lds_bits, S.lds_words, w0);
         uint32_t st = 0;
         walk_any<TRANS, IS_MATRIX, MODE_CHUNK>(tr, A.sym, off, len, init, pl.stop, sink, epsilon, unknown,
-                                                identity, step_cap(A.step_factor, len), fin, st, steps, win_row);
+                                                identity, step_cap(A.step_factor, len), fin, st, steps, win_row, s_lut);
         if (sink.dropped) fin.flags |= LANE_F_DROPPED;
         cnt.tok = sink.c_tok; cnt.sent = sink.c_sent; cnt.text = sink.c_text; cnt.status = st | sink.st;
         cnt.sev = sink.c_sev; cnt.e_pos = sink.e_pos; cnt.e_tok = sink.e_tok;
@@ -2829,7 +2898,7 @@ extern "C" int dtk_launch_clear2(void *a, uint64_t a_bytes, void *b, uint64_t b_
 }
 
 extern "C" int dtk_launch_symbolize(const uint8_t *text, const uint64_t *doc_off, uint32_t n_docs,
-                                    uint64_t total, const DtkSigmaDev *sig, uint16_t *sym, int padded,
+                                    uint64_t total, const DtkSigmaDev *sig, void *sym, int padded,
                                     const uint32_t *blk_doc, unsigned long long *n_invalid, uint32_t *rs_bits,
                                     uint32_t *ev_bits, uint32_t bit_words, void *acc, uint64_t acc_bytes,
                                     uint64_t epoch, void *stream) {
@@ -2837,25 +2906,26 @@ extern "C" int dtk_launch_symbolize(const uint8_t *text, const uint64_t *doc_off
   const uint32_t blocks = (uint32_t)((total + SYM_BLOCK_BYTES - 1) / SYM_BLOCK_BYTES);
   // ALIGNED4 may read up to 3 bytes past `total`: true for the batch's own (padded) buffer;
   // a caller-owned device buffer only qualifies when its size is a multiple of 4
-  if ((((uintptr_t)text) & 3u) == 0 && (padded || (total & 3u) == 0))
-    hipLaunchKernelGGL(k_symbolize<true>, dim3(blocks), dim3(SYM_THREADS), 0, (hipStream_t)stream, text, doc_off, n_docs,
+  const bool al4 = (((uintptr_t)text) & 3u) == 0 && (padded || (total & 3u) == 0);
+  auto go = [&](auto k) {
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(SYM_THREADS), 0, (hipStream_t)stream, text, doc_off, n_docs,
                        total, *sig, sym, blk_doc, n_invalid, rs_bits, ev_bits, bit_words, (uint4 *)acc, (uint32_t)(acc_bytes / 16),
                        (unsigned long long)epoch);
-  else
-    hipLaunchKernelGGL(k_symbolize<false>, dim3(blocks), dim3(SYM_THREADS), 0, (hipStream_t)stream, text, doc_off, n_docs,
-                       total, *sig, sym, blk_doc, n_invalid, rs_bits, ev_bits, bit_words, (uint4 *)acc, (uint32_t)(acc_bytes / 16),
-                       (unsigned long long)epoch);
+  };
+  if (sig->n_codes) { if (al4) go(k_symbolize<true, true>); else go(k_symbolize<false, true>); }
+  else { if (al4) go(k_symbolize<true, false>); else go(k_symbolize<false, false>); }
   return (int)hipGetLastError();
 }
 
+// codes: the symbol stream holds codes (DtkSym::lut) -- what the lean loop reads
 template <typename F>
-static int with_trans(const DtkTableDev *tab, F &&f) {
+static int with_trans(const DtkTableDev *tab, bool codes, F &&f) {
   if (tab->kind == DTK_KIND_MATRIX) {
     if (tab->fused) {
       MatrixFusedTrans tr{(const uint32_t *)tab->tab, tab->stride, tab->n_eps, tab->start, tab->ident_guard};
       // (da_dense: a double-array tokenizer laid out as a fused matrix -- the table's walk, datok.go's EOT rules)
       auto call = [&](auto t) { if (tab->da_dense) f(t, std::false_type{}); else f(t, std::true_type{}); };
-      if (tab->ident_guard == 0xFFFFFFFFu && !tab->plain_walk) {  // the lean loop applies
+      if (tab->ident_guard == 0xFFFFFFFFu && !tab->plain_walk && codes) {  // the lean loop applies
         MatrixLeanTrans lt;
         static_cast<MatrixFusedTrans &>(lt) = tr;
         call(lt);
@@ -2880,7 +2950,7 @@ extern "C" int dtk_launch_walk(const DtkTableDev *tab, const DtkWalkArgs *args, 
   if (args->n_docs == 0) return 0;
   const uint32_t blocks = (args->n_docs + WAVE - 1) / WAVE;
   hipStream_t s = (hipStream_t)stream;
-  return with_trans(tab, [&](auto tr, auto is_matrix) {
+  return with_trans(tab, args->sym.lut != nullptr, [&](auto tr, auto is_matrix) {
     using TR = decltype(tr);
     hipLaunchKernelGGL((k_walk_doc<TR, decltype(is_matrix)::value>), dim3(blocks), dim3(WAVE), 0, s, tr, *args,
                        tab->epsilon, tab->unknown, tab->identity);
@@ -2899,13 +2969,13 @@ extern "C" int dtk_launch_spec(const DtkTableDev *tab, const DtkWalkArgs *args, 
   const uint32_t doc_blocks = (args->n_docs + 255) / 256;
   switch (stage) {
     case 0:
-      return with_trans(tab, [&](auto tr, auto is_matrix) {
+      return with_trans(tab, args->sym.lut != nullptr, [&](auto tr, auto is_matrix) {
         using TR = decltype(tr);
         hipLaunchKernelGGL((k_spec_start<TR, decltype(is_matrix)::value>), dim3(lane_blocks), dim3(WAVE), 0, s,
                            tr, *args, *spec, tab->epsilon, tab->unknown, tab->identity);
       });
     case 6:  // first pass: start records and chunk walk in one launch
-      return with_trans(tab, [&](auto tr, auto is_matrix) {
+      return with_trans(tab, args->sym.lut != nullptr, [&](auto tr, auto is_matrix) {
         using TR = decltype(tr);
         hipLaunchKernelGGL((k_spec_both<TR, decltype(is_matrix)::value>), dim3(lane_blocks), dim3(WAVE),
                            3u * spec->lds_words * sizeof(uint32_t), s, tr, *args, *spec, tab->epsilon, tab->unknown,
@@ -2915,7 +2985,7 @@ extern "C" int dtk_launch_spec(const DtkTableDev *tab, const DtkWalkArgs *args, 
       hipLaunchKernelGGL(k_spec_link, dim3(lane_blocks256), dim3(256), 0, s, *spec);
       return (int)hipGetLastError();
     case 2:
-      return with_trans(tab, [&](auto tr, auto is_matrix) {
+      return with_trans(tab, args->sym.lut != nullptr, [&](auto tr, auto is_matrix) {
         using TR = decltype(tr);
         hipLaunchKernelGGL((k_spec_walk<TR, decltype(is_matrix)::value>), dim3(lane_blocks), dim3(WAVE),
                            3u * spec->lds_words * sizeof(uint32_t), s, tr, *args, *spec, tab->epsilon, tab->unknown,
@@ -2949,7 +3019,7 @@ extern "C" int dtk_launch_exact(const DtkTableDev *tab, const DtkExactArgs *args
   if (args->n == 0) return 0;
   const uint32_t blocks = (args->n + WAVE - 1) / WAVE;
   hipStream_t s = (hipStream_t)stream;
-  return with_trans(tab, [&](auto tr, auto is_matrix) {
+  return with_trans(tab, args->sym.lut != nullptr, [&](auto tr, auto is_matrix) {
     using TR = decltype(tr);
     if constexpr (TR::LEAN) {
       const MatrixFusedTrans base = tr;

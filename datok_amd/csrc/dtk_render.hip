@@ -51,14 +51,15 @@ __device__ __forceinline__ uint32_t row_of(const uint64_t *off, uint32_t n, uint
 // string(buf[offset:]) re-encodes the window's runes (token_writer.go:85): a byte that did not
 // decode (U+FFFD, width 1) leaves as EF BF BD.  Such bytes are the rune starts of width 1 whose
 // rune is >= 256 in the symbol stream.
-__device__ __forceinline__ bool is_invalid_byte(uint16_t e) {
+__device__ __forceinline__ bool is_invalid_byte(const DtkSym &S, uint64_t i) {
+  const uint32_t e = dtk_sym_entry(S, i);
   return DTK_SYM_WIDTH(e) == 1u && ((e >> DTK_SYM_CLS_SHIFT) & 3u) >= 2u;
 }
 
 __device__ __forceinline__ uint32_t invalid_in(const DtkRenderArgs &R, uint64_t k, uint32_t d) {
-  const uint16_t *sy = R.sym + R.doc_off[d];
+  const uint64_t sy = R.doc_off[d];
   uint32_t n = 0;
-  for (uint32_t q = R.bstart[k]; q < R.bend[k]; q++) n += is_invalid_byte(sy[q]) ? 1u : 0u;
+  for (uint32_t q = R.bstart[k]; q < R.bend[k]; q++) n += is_invalid_byte(R.sym, sy + q) ? 1u : 0u;
   return n;
 }
 
@@ -67,7 +68,7 @@ __device__ __forceinline__ Pair tok_weight(const DtkRenderArgs &R, uint64_t k) {
   if (k < R.n_tok) {
     if (R.flags & 1u) {  // surface + '\n'
       w.a = (uint64_t)(R.bend[k] - R.bstart[k]) + 1u;
-      if (R.sym) w.a += 2u * invalid_in(R, k, row_of(R.tok_off, R.n_docs, k));
+      if (R.sym.base) w.a += 2u * invalid_in(R, k, row_of(R.tok_off, R.n_docs, k));
     }
     if (R.flags & 4u) w.p = (uint64_t)dec_len(R.rstart[k]) + dec_len(R.rend[k]) + 2u;  // "s e "
   }
@@ -232,14 +233,14 @@ __global__ __launch_bounds__(RB) void k_render_tokens(DtkRenderArgs R) {
     if (o + n <= R.out_total) {
       const uint8_t *src = R.text + R.doc_off[d] + b0;
       uint8_t *dst = R.out + o;
-      if (!R.sym) {
+      if (!R.sym.base) {
         for (uint32_t i = 0; i < n; i++) dst[i] = src[i];
       } else {  // the batch has bytes that print as U+FFFD
-        const uint16_t *sy = R.sym + R.doc_off[d] + b0;
+        const uint64_t sy = R.doc_off[d] + b0;
         const uint64_t lim = R.out_total - o;
         uint64_t w = 0;
         for (uint32_t i = 0; i < n; i++) {
-          if (is_invalid_byte(sy[i])) {
+          if (is_invalid_byte(R.sym, sy + i)) {
             if (w + 3u <= lim) { dst[w] = 0xEF; dst[w + 1] = 0xBF; dst[w + 2] = 0xBD; }
             w += 3u;
           } else {
