@@ -36,7 +36,8 @@ class ModelInfo(C.Structure):
                 ("state_count", C.c_uint32), ("array_len", C.c_uint64),
                 ("n_eps_states", C.c_uint32), ("max_eps_chain", C.c_uint32),
                 ("entry_bytes", C.c_uint32), ("device_bytes", C.c_uint64),
-                ("unknown_used", C.c_uint32), ("dense_states", C.c_uint32)]
+                ("unknown_used", C.c_uint32), ("dense_states", C.c_uint32),
+                ("stream_codes", C.c_uint32)]
 
 
 class Totals(C.Structure):

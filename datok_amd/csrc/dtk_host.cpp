@@ -818,6 +818,7 @@ extern "C" int dtk_model_get_info(const dtk_model *m, dtk_model_info *o) {
   o->array_len = m->array_len; o->n_eps_states = m->n_eps_states; o->max_eps_chain = m->max_eps_chain;
   o->entry_bytes = m->tab.entry_bytes; o->device_bytes = m->device_bytes; o->unknown_used = m->unknown_used;
   o->dense_states = m->dense_states;
+  o->stream_codes = m->sig.n_codes;
   return DTK_OK;
 }
 

@@ -107,6 +107,8 @@ typedef struct {
   uint32_t unknown_used; /* 1 if any state has an arc on the unknown symbol */
   uint32_t dense_states; /* double array only: its states, if its transitions were laid out as a matrix on the
                           * device at load (entry_bytes is then 4); 0: the {base, check} pairs are walked */
+  uint32_t stream_codes; /* distinct symbol-stream entries of the model if they fit a byte (the stream is then one
+                          * code per input byte and the lean loop may apply); 0: 16-bit entries, general loop */
 } dtk_model_info;
 int dtk_model_get_info(const dtk_model *m, dtk_model_info *out);
 

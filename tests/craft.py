@@ -41,22 +41,23 @@ def _automaton(triple):
     return arcs
 
 
-def _sigma_bytes():
-    return "".join(SIGMA).encode("utf-8")
+def _sigma_bytes(sigma=None):
+    return "".join(sigma or SIGMA).encode("utf-8")
 
 
 def matok(triple=False) -> bytes:
     return matok_from(_automaton(triple))
 
 
-def matok_from(arcs) -> bytes:
-    """The `.matok` image of an arc table  state -> {symbol: (target, nontoken)}  (states 1..n, 1 = start)."""
-    n, s = max(max(arcs), max(to for row in arcs.values() for to, _ in row.values())), len(SIGMA)
+def matok_from(arcs, sigma=None) -> bytes:
+    """The `.matok` image of an arc table  state -> {symbol: (target, nontoken)}  (states 1..n, 1 = start);
+    sigma: SIGMA with more characters appended (symbol = index)."""
+    n, s = max(max(arcs), max(to for row in arcs.values() for to, _ in row.values())), len(sigma or SIGMA)
     arr = [0] * ((n + 1) * s)
     for t, row in arcs.items():
         for a, (to, nontoken) in row.items():
             arr[(a - 1) * n + t] = to | (FIRSTBIT if nontoken else 0)      # matrix.go:85-90
-    raw = b"MATOK" + struct.pack("<HHHHIH", 1, EPS, UNKNOWN, IDENTITY, n, s) + _sigma_bytes() + b"M"
+    raw = b"MATOK" + struct.pack("<HHHHIH", 1, EPS, UNKNOWN, IDENTITY, n, s) + _sigma_bytes(sigma) + b"M"
     raw += struct.pack("<%dI" % len(arr), *arr)
     return gzip.compress(raw)
 
@@ -65,9 +66,9 @@ def datok(triple=False) -> bytes:
     return datok_from(_automaton(triple))
 
 
-def datok_from(arcs) -> bytes:
+def datok_from(arcs, sigma=None) -> bytes:
     """The `.datok` image of the same kind of arc table (every arc slot "separate")."""
-    n, s = max(max(arcs), max(to for row in arcs.values() for to, _ in row.values())), len(SIGMA)
+    n, s = max(max(arcs), max(to for row in arcs.values() for to, _ in row.values())), len(sigma or SIGMA)
     size = n + 1 + (n + 1) * s
     base = [0] * (size + s + 2)
     check = [0] * (size + s + 2)
@@ -85,7 +86,7 @@ def datok_from(arcs) -> bytes:
             top = max(top, b + a)
     check[1] = top                                                          # datok.go:328-335: the array's size
     pairs = [x for i in range(len(base)) for x in (base[i], check[i])]
-    raw = b"DATOK" + struct.pack("<HHHHHHI", 1, EPS, UNKNOWN, IDENTITY, s, s, len(pairs)) + _sigma_bytes() + b"T"
+    raw = b"DATOK" + struct.pack("<HHHHHHI", 1, EPS, UNKNOWN, IDENTITY, s, s, len(pairs)) + _sigma_bytes(sigma) + b"T"
     raw += struct.pack("<%dI" % len(pairs), *pairs)
     return gzip.compress(raw)
 

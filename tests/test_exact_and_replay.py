@@ -287,3 +287,47 @@ def test_random_automata_equal_the_oracle(tmp_path, seed):
                                 if est == 0 and not (int(res.status[d]) & ~datok_amd.ST_EMPTY_TEXT):
                                     assert bytes(data[int(o[d]):int(o[d + 1])]) == exp, (kind, chunk, flags, bits, doc)
     assert compared > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["matok", "datok"])
+def test_symbol_stream_of_entries_for_a_sigma_beyond_the_code_table(tmp_path, kind):
+    """The symbol stream holds one code per input byte where the model's distinct entries fit a byte (the shipped
+    tokenizers: 176 symbols, some 190 entries; `dtk_model_info.stream_codes`), else the 16-bit entries themselves,
+    walked by the general loop.  A tokenizer with 300 more characters in its sigma takes that path; arcs on some of
+    them, documents that mix them with the usual letters, invalid bytes and runes outside the sigma."""
+    import datok_amd
+    from datok_amd import corpus
+    extra = [chr(0x4E00 + i) for i in range(300)]
+    sigma = craft.SIGMA + extra
+    rng = np.random.default_rng(7)
+    arcs = craft._automaton(False)
+    for row in arcs.values():            # forty of the new characters are letters like "a"
+        if craft.A in row:
+            for j in range(40):
+                row[len(craft.SIGMA) + j] = row[craft.A]
+    blob = getattr(craft, kind + "_from")(arcs, sigma)
+    path = tmp_path / ("big." + kind)
+    path.write_bytes(blob)
+    tok, om = datok_amd.load_tokenizer_file(str(path)), _oracle(blob)
+    assert tok is not None and tok.info["stream_codes"] == 0, tok.info
+    small = datok_amd.load_tokenizer_file(os.path.join(MODELS, "tokenizer_de.matok"))
+    assert 0 < small.info["stream_codes"] < 255, small.info
+    raw = [c.encode() for c in extra[:40]] + [b"\xff", b"\xe4\xb8", "鿿".encode(), "\U0001F600".encode()]
+    docs = craft.random_documents(rng, 200, 120, raw)
+    text, off = corpus.concat_docs(docs)
+    compared = 0
+    for chunk, warm in ((0, 0), (16, 4), (None, 16)):
+        with datok_amd.Batch(len(text), len(docs)) as b:
+            if chunk is not None:
+                b.set_chunking(chunk, warm, extend=0)
+            b.set_input(text, off)
+            b.run(tok, 0)
+            res = b.result()
+            compared += assert_batch_equals_oracle(om, res, text, off, 0)
+            data, o = b.render(3)
+            for d, doc in enumerate(docs):
+                exp, est = om.transduce(doc, 3)
+                if est == 0 and not (int(res.status[d]) & ~datok_amd.ST_EMPTY_TEXT):
+                    assert bytes(data[int(o[d]):int(o[d + 1])]) == exp, (chunk, doc)
+    assert compared > 50
