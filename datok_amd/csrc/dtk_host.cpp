@@ -205,9 +205,12 @@ static int upload(dtk_model *m, const void *tab, size_t tab_bytes) {
     };
     const uint32_t ident = m->identity < 0 ? 0u : colof(m->identity);
     std::vector<uint8_t> bytes(256 + nr);
-    for (uint32_t i = 0; i < 256; i++)  // matrix.go:421-426; a rune of 128..255 takes two bytes
-      bytes[i] = code_of((ascii_dev[i] & DTK_SYM_MASK) | (i == DTK_EOT ? 1u << DTK_SYM_CLS_SHIFT : 0u) |
-                         ((i < 128 ? 1u : 2u) << DTK_SYM_W_SHIFT));
+    for (uint32_t i = 0; i < 256; i++) {  // matrix.go:421-426; a rune of 128..255 takes two bytes
+      const uint32_t e = (ascii_dev[i] & DTK_SYM_MASK) | (i == DTK_EOT ? 1u << DTK_SYM_CLS_SHIFT : 0u) |
+                         ((i < 128 ? 1u : 2u) << DTK_SYM_W_SHIFT);
+      // (the code of a byte < 128 is the byte: the symboliser copies those, k_symbolize's light path)
+      if (i < 128) { entries.push_back((uint16_t)e); bytes[i] = (uint8_t)i; } else bytes[i] = code_of(e);
+    }
     uint32_t fffd = (ident & DTK_SYM_MASK) | (3u << DTK_SYM_CLS_SHIFT);
     for (size_t i = 0; i < nr; i++) {
       const uint32_t r = m->sigma_runes[first + i], w = r < 0x800u ? 2u : (r < 0x10000u ? 3u : 4u);

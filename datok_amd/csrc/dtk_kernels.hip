@@ -137,8 +137,7 @@ __global__ __launch_bounds__(SYM_THREADS) void k_symbolize(const uint8_t *__rest
   for (uint32_t i = tid; i < 256u; i += SYM_THREADS) {
     // matrix.go:421-426: runes < 256 go through sigmaASCII; rune 4 is EOT
     if (SYM8) {
-      lat[i] = sig.code_lt256[i];
-      if (i < 128u) lut[i] = sig.code_lt256[i];
+      lat[i] = sig.code_lt256[i];  // (lut is not used: the code of a byte < 128 is the byte)
       if (sig_lds && i < sig.n_runes) { s_runes[i] = sig.runes[i]; s_syms[i] = sig.code_runes[i]; }
     } else {
       const uint32_t e = (sig.ascii[i] & DTK_SYM_MASK) | (i == DTK_EOT ? (1u << DTK_SYM_CLS_SHIFT) : 0u);
@@ -208,23 +207,26 @@ __global__ __launch_bounds__(SYM_THREADS) void k_symbolize(const uint8_t *__rest
       constexpr bool FULL = decltype(full_tag)::value;  // a whole block, entries 16-byte aligned
       const uint32_t i0 = half * SYM_HALF + it * SYM_TILE + lane * 8u;  // my 8 bytes (offset in the block)
       const uint32_t w0 = s_txt[1 + (i0 >> 2)], w1 = s_txt[2 + (i0 >> 2)];
-      const uint32_t e0 = lut[w0 & 0x7Fu], e1 = lut[(w0 >> 8) & 0x7Fu];
-      const uint32_t e2 = lut[(w0 >> 16) & 0x7Fu], e3 = lut[(w0 >> 24) & 0x7Fu];
-      const uint32_t e4 = lut[w1 & 0x7Fu], e5 = lut[(w1 >> 8) & 0x7Fu];
-      const uint32_t e6 = lut[(w1 >> 16) & 0x7Fu], e7 = lut[(w1 >> 24) & 0x7Fu];
       uint32_t left = 8u;
       if (!FULL) left = i0 < n_here ? (n_here - i0 >= 8u ? 8u : n_here - i0) : 0u;
-      if (FULL || (left == 8u && sym16)) {
-        if (SYM8)
-          *reinterpret_cast<uint2 *>(sym8 + block_start + i0) =
-              make_uint2(e0 | (e1 << 8) | (e2 << 16) | (e3 << 24), e4 | (e5 << 8) | (e6 << 16) | (e7 << 24));
-        else
+      if (SYM8) {
+        // the code of a byte < 128 is the byte itself (upload()): the light path is a copy
+        if (FULL || (left == 8u && sym16)) {
+          *reinterpret_cast<uint2 *>(sym8 + block_start + i0) = make_uint2(w0, w1);
+        } else {
+          for (uint32_t j = 0; j < left; j++) sym8[block_start + i0 + j] = (uint8_t)((j < 4u ? w0 >> (8u * j) : w1 >> (8u * j - 32u)));
+        }
+      } else {
+        const uint32_t e0 = lut[w0 & 0x7Fu], e1 = lut[(w0 >> 8) & 0x7Fu];
+        const uint32_t e2 = lut[(w0 >> 16) & 0x7Fu], e3 = lut[(w0 >> 24) & 0x7Fu];
+        const uint32_t e4 = lut[w1 & 0x7Fu], e5 = lut[(w1 >> 8) & 0x7Fu];
+        const uint32_t e6 = lut[(w1 >> 16) & 0x7Fu], e7 = lut[(w1 >> 24) & 0x7Fu];
+        if (FULL || (left == 8u && sym16)) {
           *reinterpret_cast<uint4 *>(sym + block_start + i0) =
               make_uint4(e0 | (e1 << 16), e2 | (e3 << 16), e4 | (e5 << 16), e6 | (e7 << 16));
-      } else {
-        const uint32_t o[8] = {e0, e1, e2, e3, e4, e5, e6, e7};
-        for (uint32_t j = 0; j < left; j++) {
-          if (SYM8) sym8[block_start + i0 + j] = (uint8_t)o[j]; else sym[block_start + i0 + j] = (uint16_t)o[j];
+        } else {
+          const uint32_t o[8] = {e0, e1, e2, e3, e4, e5, e6, e7};
+          for (uint32_t j = 0; j < left; j++) sym[block_start + i0 + j] = (uint16_t)o[j];
         }
       }
       // one bit per byte: bytes < 0x80 start a rune (the others are decided one by one below)
