@@ -349,7 +349,7 @@ def main():
             "metric": "input MB/s tokenized, tokenizer_de.matok",
             "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u32 table cells, u16 symbols", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "u32 table cells, u8 symbol codes", "data": "synthetic",
             "config": {"workload": workload % (n_docs, args.doc_bytes),
                        "docs_per_gpu": n_docs, "doc_bytes": args.doc_bytes,
                        "parallelism": "documents sharded over %d GPU(s), no data-path collective" % world,

@@ -25,7 +25,7 @@
 #define DTK_WIN 32u
 #define DTK_WIN_ROW 36u
 // ---- the stream in memory: one BYTE per input byte where the model's entries fit a code table (DtkSigmaDev::n_codes:
-// the shipped models have 176 symbols and some 190 distinct entries), else the 16-bit entries themselves.  A code
+// the shipped models have some 170 symbols and 200 distinct entries), else the 16-bit entries themselves.  A code
 // is an index into `lut` (256 entries); DTK_SYM_CONT = no rune starts here.  Half the stream's traffic -- it was 44 %
 // of what a batch moves -- and a window of twice the positions in the same LDS (the lean walk keeps codes in its rows).
 #define DTK_SYM_CONT 0xFFu

@@ -293,7 +293,7 @@ def test_random_automata_equal_the_oracle(tmp_path, seed):
 @pytest.mark.parametrize("kind", ["matok", "datok"])
 def test_symbol_stream_of_entries_for_a_sigma_beyond_the_code_table(tmp_path, kind):
     """The symbol stream holds one code per input byte where the model's distinct entries fit a byte (the shipped
-    tokenizers: 176 symbols, some 190 entries; `dtk_model_info.stream_codes`), else the 16-bit entries themselves,
+    tokenizers: some 170 symbols, 200 entries; `dtk_model_info.stream_codes`), else the 16-bit entries themselves,
     walked by the general loop.  A tokenizer with 300 more characters in its sigma takes that path; arcs on some of
     them, documents that mix them with the usual letters, invalid bytes and runes outside the sigma."""
     import datok_amd
