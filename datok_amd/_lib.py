@@ -23,7 +23,7 @@ EXPORTS = [
     "dtk_batch_run", "dtk_batch_sync", "dtk_batch_stream", "dtk_batch_totals",
     "dtk_batch_set_profiling", "dtk_batch_stage_ms", "dtk_batch_set_chunking", "dtk_batch_set_warm_extend",
     "dtk_batch_result_device", "dtk_batch_result_host", "dtk_transduce", "dtk_free",
-    "dtk_foma_to_matok", "dtk_transduce_replay", "dtk_batch_render_device", "dtk_batch_render_host",
+    "dtk_foma_to_matok", "dtk_foma_to_datok", "dtk_transduce_replay", "dtk_batch_render_device", "dtk_batch_render_host",
     "dtk_batch_status_host", "dtk_transduce_release", "dtk_transduce_result",
     "dtk_pipeline_create", "dtk_pipeline_free", "dtk_pipeline_set_chunking", "dtk_pipeline_run",
     "dtk_pinned_alloc", "dtk_pinned_free",
@@ -137,6 +137,8 @@ def lib():
     L.dtk_batch_status_host.argtypes = [vp, vp, u32]
     L.dtk_foma_to_matok.argtypes = [vp, C.c_size_t, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.dtk_foma_to_matok.restype = C.c_int
+    L.dtk_foma_to_datok.argtypes = [vp, C.c_size_t, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.dtk_foma_to_datok.restype = C.c_int
     L.dtk_free.argtypes = [vp]
     L.dtk_free.restype = None
     L.dtk_pipeline_create.argtypes = [u64, u32, u32, C.POINTER(vp)]

@@ -5,8 +5,7 @@
 //   datok convert  -i <foma.fst> -o <tokenizer> [-d]
 //
 // `tokenize` walks and renders on the GPU (dtk_transduce); the input stream is one document,
-// U+0004 ends a text inside it.  `convert` is host only; -d (double array, datok.go:95-250) is an
-// offline construction that is not provided.
+// U+0004 ends a text inside it.  `convert` is host only; -d: the double array (ToDoubleArray, datok.go:82-238).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -56,10 +55,6 @@ static int cmd_convert(int argc, char **argv) {
   }
   if (foma.empty()) return usage("missing flags: --foma=STRING");
   if (tok.empty()) return usage("missing flags: --tokenizer=STRING");
-  if (da) {
-    std::fprintf(stderr, "datok: the double array construction (ToDoubleArray) is not provided; convert to a matrix\n");
-    return 1;
-  }
   FILE *f = std::fopen(foma.c_str(), "rb");
   std::vector<uint8_t> gz;
   if (!f || !read_all(f, gz)) {
@@ -70,7 +65,8 @@ static int cmd_convert(int argc, char **argv) {
   std::fclose(f);
   void *img = nullptr;
   size_t n = 0;
-  const int rc = dtk_foma_to_matok(gz.data(), gz.size(), &img, &n);
+  const int rc = da ? dtk_foma_to_datok(gz.data(), gz.size(), &img, &n)  // cmd/datok.go:58-66
+                    : dtk_foma_to_matok(gz.data(), gz.size(), &img, &n);
   if (rc != DTK_OK) {
     std::fprintf(stderr, "Unable to load foma file: %s\n", dtk_strerror(rc));
     return 1;

@@ -5,6 +5,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -531,9 +532,9 @@ static int build_datok(dtk_model *m, const std::vector<uint8_t> &raw) {
 //
 // LoadFomaFile/ParseFoma (fomafile.go:56-450) followed by Automaton.ToMatrix (matrix.go:30-99):
 // a deterministic, epsilon-free Foma net in text form becomes the matrix tokenizer.  The
-// double-array construction (ToDoubleArray, datok.go:95-250) is an offline step and not built.
+// double-array construction (ToDoubleArray, datok.go:82-238) follows further down (dtk_foma_to_datok).
 namespace {
-struct FomaArc { int32_t end; bool nontoken; };
+struct FomaArc { int32_t end; bool nontoken; bool tokenend = false; };
 struct FomaNet {
   int epsilon = -1, unknown = -1, identity = -1, final_sym = -1, tokenend = -1;
   int sigma_count = 0, state_count = -1;
@@ -646,16 +647,16 @@ static int parse_foma(const std::vector<uint8_t> &raw, FomaNet &net) {
       } else if (nf == 3) { in_sym = e[0]; out_sym = e[1]; end = e[2]; }
       else if (nf == 2) { in_sym = out_sym = e[0]; end = e[1]; }
       const int is = in_sym + 1, os = out_sym + 1;
-      bool nontoken = false;
+      bool nontoken = false, tokenend = false;
       if (is != os) {
-        if (os == net.tokenend && is == net.epsilon) { /* token boundary, kept under epsilon */ }
+        if (os == net.tokenend && is == net.epsilon) tokenend = true;  // token boundary, kept under epsilon (fomafile.go:293)
         else if (os == net.epsilon) nontoken = true;
         else return DTK_E_MODEL;  // unsupported transition
       } else if (is == net.tokenend) continue;
       else if (is == net.epsilon) return DTK_E_MODEL;  // general epsilon transitions
       else if (is >= 0 && (size_t)is < net.mcs.size() && net.mcs[(size_t)is]) continue;
       if (state < 0 || state + 1 > net.state_count || end < -1 || end + 1 > net.state_count) return DTK_E_MODEL;
-      if (is >= 0) set_arc(state + 1, is, FomaArc{end + 1, nontoken});
+      if (is >= 0) set_arc(state + 1, is, FomaArc{end + 1, nontoken, tokenend});
       if (fin == 1) set_arc(state + 1, net.final_sym, FomaArc{0, false});
     }
   }
@@ -722,6 +723,25 @@ static void put_rune(std::vector<uint8_t> &o, uint32_t r) {  // bufio.Writer.Wri
 }
 }  // namespace
 
+// gzip.NewWriter(f) over a finished image; the caller frees *out
+static int gzip_image(const std::vector<uint8_t> &img, void **out, size_t *out_n) {
+  z_stream zs;
+  memset(&zs, 0, sizeof zs);
+  if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 16 + MAX_WBITS, 8, Z_DEFAULT_STRATEGY) != Z_OK)
+    return DTK_E_NOMEM;
+  const uLong bound = deflateBound(&zs, (uLong)img.size());
+  uint8_t *buf = (uint8_t *)malloc(bound);
+  if (!buf) { deflateEnd(&zs); return DTK_E_NOMEM; }
+  zs.next_in = const_cast<uint8_t *>(img.data()); zs.avail_in = (uInt)img.size();
+  zs.next_out = buf; zs.avail_out = (uInt)bound;
+  const int rc = deflate(&zs, Z_FINISH);
+  const size_t have = bound - zs.avail_out;
+  deflateEnd(&zs);
+  if (rc != Z_STREAM_END) { free(buf); return DTK_E_NOMEM; }
+  *out = buf; *out_n = have;
+  return DTK_OK;
+}
+
 // `datok convert -f foma -t file` without --double-array (cmd/datok.go:50-70): LoadFomaFile,
 // ToMatrix, then MatrixTokenizer.Save/WriteTo (matrix.go:107-210) into a gzip image.  Host only.
 extern "C" int dtk_foma_to_matok(const void *gz_bytes, size_t n, void **out, size_t *out_n) {
@@ -749,22 +769,101 @@ extern "C" int dtk_foma_to_matok(const void *gz_bytes, size_t n, void **out, siz
   for (uint32_t r : list) put_rune(img, r);
   img.push_back('M');
   for (uint32_t x : arr) p32(x);
-  // gzip.NewWriter(f)
-  z_stream zs;
-  memset(&zs, 0, sizeof zs);
-  if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 16 + MAX_WBITS, 8, Z_DEFAULT_STRATEGY) != Z_OK)
-    return DTK_E_NOMEM;
-  const uLong bound = deflateBound(&zs, (uLong)img.size());
-  uint8_t *buf = (uint8_t *)malloc(bound);
-  if (!buf) { deflateEnd(&zs); return DTK_E_NOMEM; }
-  zs.next_in = img.data(); zs.avail_in = (uInt)img.size();
-  zs.next_out = buf; zs.avail_out = (uInt)bound;
-  rc = deflate(&zs, Z_FINISH);
-  const size_t have = bound - zs.avail_out;
-  deflateEnd(&zs);
-  if (rc != Z_STREAM_END) { free(buf); return DTK_E_NOMEM; }
-  *out = buf; *out_n = have;
-  return DTK_OK;
+  return gzip_image(img, out, out_n);
+}
+
+// `datok convert ... --double-array` (cmd/datok.go:50-70): LoadFomaFile, Automaton.ToDoubleArray (datok.go:82-238,
+// after Mizobuchi et al. 2000 with the xCheckSkipNiu search, datok.go:385-406), DaTokenizer.WriteTo (datok.go:502-596)
+// into a gzip image.  Host only.
+// The reference walks each state's outgoing symbols in Go's map order (getSet, fomafile.go:488-495, "sort not
+// required") -- random per run, and the order decides which state is laid out next and so where everything after it
+// lands: two runs of the reference give different arrays for the same net.  Here the symbols are taken in ascending
+// order; the image is one of those the reference can produce, not a particular one.
+extern "C" int dtk_foma_to_datok(const void *gz_bytes, size_t n, void **out, size_t *out_n) {
+  if (!gz_bytes || !out || !out_n) return DTK_E_ARG;
+  *out = nullptr; *out_n = 0;
+  std::vector<uint8_t> raw;
+  int rc = gunzip((const uint8_t *)gz_bytes, n, raw);
+  if (rc != DTK_OK) return rc;
+  if (raw.size() < 10 || memcmp(raw.data(), "##foma-net", 10) != 0) return DTK_E_FORMAT;
+  FomaNet net;
+  rc = parse_foma(raw, net);
+  if (rc != DTK_OK) return rc;
+  const uint32_t final_ = (uint32_t)net.final_sym;
+  struct BC { uint32_t base = 0, check = 0; };
+  std::vector<BC> arr;
+  auto resize = [&](size_t l) { if (arr.size() <= l) arr.resize(arr.size() + l); };  // datok.go:257-263
+  resize(final_);
+  int64_t max_size = 0;
+  // table: state of the net -> its index in the array, in the order of discovery (datok.go:122-127)
+  std::vector<uint32_t> target((size_t)net.state_count + 2, 0);
+  std::vector<uint32_t> queue{1};
+  target[1] = 1;
+  std::vector<int> A;
+  for (size_t mark = 0; mark < queue.size(); mark++) {
+    const uint32_t s = queue[mark], t = target[s];
+    A.clear();
+    for (auto &e : net.arcs[s]) A.push_back(e.first);
+    std::sort(A.begin(), A.end());
+    // xCheckSkipNiu, datok.go:385-406
+    uint32_t base = 1;
+    if (A.size() >= 3) base = (uint32_t)std::fabs((double)(max_size - 1) * .9) + 1;
+    for (;;) {
+      resize((size_t)base + final_ + 1);
+      bool clash = false;
+      for (int a : A)
+        if ((arr[(size_t)base + (size_t)a].check & DTK_RESTBIT) != 0) { clash = true; break; }
+      if (!clash) break;
+      base++;
+    }
+    if (base > DTK_RESTBIT) return DTK_E_MODEL;
+    arr[t].base = base;
+    for (int a : A) {
+      const FomaArc *arc = nullptr;
+      for (auto &e : net.arcs[s]) if (e.first == a) arc = &e.second;
+      if ((uint32_t)a != final_) {
+        const uint32_t s1 = (uint32_t)arc->end, t1 = base + (uint32_t)a;
+        arr[t1].check = t;
+        if (max_size < (int64_t)t1) max_size = t1;
+        if (arc->nontoken) arr[t1].check |= DTK_FIRSTBIT;
+        if (arc->tokenend) arr[t1].check |= DTK_SECONDBIT;
+        if (s1 < 1 || s1 > (uint32_t)net.state_count) return DTK_E_MODEL;
+        if (target[s1] == 0) { target[s1] = t1; queue.push_back(s1); }  // no representative yet: this index is the state
+        else arr[t1].base = target[s1] | DTK_FIRSTBIT;                 // separate: points to the representative
+      } else {
+        arr[(size_t)base + final_].check = t;
+        if (max_size < (int64_t)base + final_) max_size = (int64_t)base + final_;  // datok.go:215-218
+      }
+    }
+  }
+  // datok.go:224-231: the size in check(1), a little larger than needed so that no lookup has to test a bound
+  const size_t len = (size_t)max_size + final_;
+  if (arr.size() <= 1) arr.resize(2);
+  arr[1].check = (uint32_t)len;
+  if (arr.size() < len) arr.resize(arr.size() + final_);
+  arr.resize(len);
+  // WriteTo: the sigma list ends at the largest character symbol (datok.go:515-528)
+  // (dat.sigma maps rune -> symbol: of two symbols for one rune the later one stays, datok.go:104-109)
+  std::vector<std::pair<uint32_t, int>> by_rune;
+  for (auto &c : net.chars) {
+    bool found = false;
+    for (auto &e : by_rune) if (e.first == c.second) { e.second = c.first; found = true; }
+    if (!found) by_rune.emplace_back(c.second, c.first);
+  }
+  uint32_t max = 0;
+  for (auto &e : by_rune) max = std::max<uint32_t>(max, (uint32_t)e.second);
+  std::vector<uint32_t> list(max + 1, 0);
+  for (auto &e : by_rune) list[(size_t)e.second] = e.first;
+  std::vector<uint8_t> img;
+  auto p16 = [&](uint32_t v) { img.push_back((uint8_t)v); img.push_back((uint8_t)(v >> 8)); };
+  auto p32 = [&](uint32_t v) { p16(v & 0xFFFF); p16(v >> 16); };
+  img.insert(img.end(), {'D', 'A', 'T', 'O', 'K'});
+  p16(1); p16((uint32_t)net.epsilon); p16((uint32_t)net.unknown); p16((uint32_t)net.identity);
+  p16(final_); p16(max + 1); p32((uint32_t)(arr.size() * 2));
+  for (uint32_t r : list) put_rune(img, r);
+  img.push_back('T');
+  for (auto &bc : arr) { p32(bc.base); p32(bc.check); }
+  return gzip_image(img, out, out_n);
 }
 
 extern "C" int dtk_model_load_mem(const void *gz_bytes, size_t n, dtk_model **out) {

@@ -521,6 +521,20 @@ def foma_to_matok(foma_gz: bytes) -> bytes:
         lib().dtk_free(out)
 
 
+def foma_to_datok(foma_gz: bytes) -> bytes:
+    """`datok convert --double-array` (cmd/datok.go:50-70): LoadFomaFile + ToDoubleArray (datok.go:82-238) + Save.
+
+    The reference's layout depends on Go's map iteration order; this one takes a state's symbols in ascending order.
+    Host only.
+    """
+    out, n = C.c_void_p(), C.c_size_t()
+    check(lib().dtk_foma_to_datok(foma_gz, len(foma_gz), C.byref(out), C.byref(n)), "foma_to_datok")
+    try:
+        return C.string_at(out, n.value)
+    finally:
+        lib().dtk_free(out)
+
+
 def load_foma_file(path):
     """LoadFomaFile(path).ToMatrix() (fomafile.go:56-75, matrix.go:30-99) on the device."""
     return load_tokenizer_file(path)

@@ -91,8 +91,13 @@ void dtk_model_free(dtk_model *m);
  * (fomafile.go:56-450, matrix.go:30-99), i.e. what the reference's tests build their tiny tokenizers with.
  * dtk_foma_to_matok is `datok convert` without --double-array (cmd/datok.go:50-70): the same conversion
  * followed by MatrixTokenizer.Save (matrix.go:107-210) into a gzip image (*out, free with dtk_free).
- * Host only: needs no device.  ToDoubleArray (datok.go:95-250) is not provided. */
+ * Host only: needs no device.
+ * dtk_foma_to_datok is `datok convert --double-array`: Automaton.ToDoubleArray (datok.go:82-238, Mizobuchi et al. 2000
+ * with the xCheckSkipNiu search) followed by DaTokenizer.Save (datok.go:485-596).  The reference lays the states out
+ * in the order Go's map iteration hands it their symbols (fomafile.go:488-495) -- two runs give two arrays; here the
+ * symbols are taken in ascending order, so the image is one the reference can produce, not a particular one. */
 int dtk_foma_to_matok(const void *gz_bytes, size_t n, void **out, size_t *out_n);
+int dtk_foma_to_datok(const void *gz_bytes, size_t n, void **out, size_t *out_n);
 const char *dtk_model_type(const dtk_model *m); /* Tokenizer.Type(): "MATOK" / "DATOK" (matrix.go:102, datok.go:252) */
 
 typedef struct {

@@ -331,3 +331,27 @@ def test_symbol_stream_of_entries_for_a_sigma_beyond_the_code_table(tmp_path, ki
                 if est == 0 and not (int(res.status[d]) & ~datok_amd.ST_EMPTY_TEXT):
                     assert bytes(data[int(o[d]):int(o[d + 1])]) == exp, (chunk, doc)
     assert compared > 50
+
+
+@pytest.mark.gpu
+def test_converted_double_array_on_the_device(tmp_path):
+    """`datok convert --double-array` (dtk_foma_to_datok, host code) of the shipped tokenizer_de.fst, loaded like any
+    .datok file (dense layout and all) and walked on the device: every offset equal to the oracle's walk of the same
+    image, and -- no U+0004 in these documents -- to the matrix tokenizer's result."""
+    import datok_amd
+    from datok_amd import corpus
+    with open(os.path.join(MODELS, "tokenizer_de.fst"), "rb") as f:
+        img = datok_amd.foma_to_datok(f.read())
+    path = tmp_path / "converted.datok"
+    path.write_bytes(img)
+    tok, om = datok_amd.load_tokenizer_file(str(path)), _oracle(img)
+    assert tok.type() == "DATOK" and tok.info["dense_states"] > 0
+    text, off = corpus.german_docs(256, 2048, seed=21)
+    mat = datok_amd.load_tokenizer_file(os.path.join(MODELS, "tokenizer_de.matok"))
+    with datok_amd.Batch(len(text), len(off) - 1) as b, datok_amd.Batch(len(text), len(off) - 1) as bm:
+        b.set_input(text, off); bm.set_input(text, off)
+        b.run(tok, 0); bm.run(mat, 0)
+        res, resm = b.result(), bm.result()
+        assert assert_batch_equals_oracle(om, res, text, off, 0) == len(off) - 1
+        for k in ("tok_off", "sent_off", "tok_rstart", "tok_rend", "tok_bstart", "tok_bend", "sent"):
+            assert np.array_equal(getattr(res, k), getattr(resm, k)), k
