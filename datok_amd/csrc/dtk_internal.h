@@ -307,7 +307,9 @@ int dtk_launch_symbolize(const uint8_t *text, const uint64_t *doc_off, uint32_t 
                          uint64_t total, const struct DtkSigmaDev *sig, void *sym, int padded,
                          const uint32_t *blk_doc, unsigned long long *n_invalid, uint32_t *rs_bits,
                          uint32_t *ev_bits, uint32_t bit_words, void *acc, uint64_t acc_bytes, uint64_t epoch, void *stream);
+#ifndef DTK_SYM_BLOCK_BYTES
 #define DTK_SYM_BLOCK_BYTES 4096u  // input bytes per symbolise block (blk_doc granularity)
+#endif
 int dtk_launch_walk(const struct DtkTableDev *tab, const struct DtkWalkArgs *args, void *stream);
 int dtk_launch_spec(const struct DtkTableDev *tab, const struct DtkWalkArgs *args,
                     const struct DtkSpecArgs *spec, int stage, uint32_t cmp_mask, uint32_t *redo_out,

@@ -95,7 +95,7 @@ __device__ __forceinline__ uint32_t doc_of(const uint64_t *__restrict__ doc_off,
 #define SYM_SIG_LDS 64u  // runes >= 256 of the sigma kept in LDS (40 in the shipped models)
 #define SYM_HALF 1024u  // bytes per wave (its queue of bytes >= 0x80: 2 B of LDS per byte)
 #define SYM_THREADS (WAVE * (SYM_BLOCK_BYTES / SYM_HALF))  // 256: four waves per 4 KiB block
-#define SYM_DOFF 256u  // document offsets of a block kept in LDS (documents of 16 bytes on average and longer)
+#define SYM_DOFF (SYM_BLOCK_BYTES / 16u)  // document offsets of a block kept in LDS (documents of 16 bytes on average and longer)
 
 // SYM8: the stream holds one code per byte (DtkSigmaDev's code table) instead of the 16-bit entries; lut / lat then
 // hold codes too.
