@@ -345,7 +345,9 @@ def test_converted_double_array_on_the_device(tmp_path):
     path = tmp_path / "converted.datok"
     path.write_bytes(img)
     tok, om = datok_amd.load_tokenizer_file(str(path)), _oracle(img)
-    assert tok.type() == "DATOK" and tok.info["dense_states"] > 0
+    assert tok.type() == "DATOK"
+    if not any(os.environ.get(k) for k in ("DATOK_NO_DENSE", "DATOK_NO_FUSED", "DATOK_FORCE_WIDE")):
+        assert tok.info["dense_states"] > 0
     text, off = corpus.german_docs(256, 2048, seed=21)
     mat = datok_amd.load_tokenizer_file(os.path.join(MODELS, "tokenizer_de.matok"))
     with datok_amd.Batch(len(text), len(off) - 1) as b, datok_amd.Batch(len(text), len(off) - 1) as bm:
