@@ -312,7 +312,8 @@ def test_symbol_stream_of_entries_for_a_sigma_beyond_the_code_table(tmp_path, ki
     tok, om = datok_amd.load_tokenizer_file(str(path)), _oracle(blob)
     assert tok is not None and tok.info["stream_codes"] == 0, tok.info
     small = datok_amd.load_tokenizer_file(os.path.join(MODELS, "tokenizer_de.matok"))
-    assert 0 < small.info["stream_codes"] < 255, small.info
+    if not os.environ.get("DATOK_SYM16"):      # (the switch that forces 16-bit entries for every model)
+        assert 0 < small.info["stream_codes"] < 255, small.info
     raw = [c.encode() for c in extra[:40]] + [b"\xff", b"\xe4\xb8", "鿿".encode(), "\U0001F600".encode()]
     docs = craft.random_documents(rng, 200, 120, raw)
     text, off = corpus.concat_docs(docs)
