@@ -2,8 +2,9 @@
 """Random small automata (tests/craft.py writes them in both file formats) x random documents x chunkings x flags:
 every document -- offsets, status and the rendered writer output -- against the oracle.  The shipped models only
 exercise what real tokenizers do; this looks for constructs nobody wrote a test for.
-usage: fuzz_automata.py [automata] [first seed] [wide]     (on an MI355X)
-wide: up to 24 states, documents up to 400 bytes with invalid UTF-8 and 3- and 4-byte runes"""
+usage: fuzz_automata.py [automata] [first seed] [wide|long]     (on an MI355X)
+wide: up to 24 states, documents up to 400 bytes with invalid UTF-8 and 3- and 4-byte runes
+long: four more documents of 40-300 KB glued from the others (segment compaction, thousands of lanes per document)"""
 import gzip
 import os
 import sys
@@ -22,12 +23,15 @@ from parity import assert_batch_equals_oracle  # noqa: E402
 n_auto = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 wide = len(sys.argv) > 3 and sys.argv[3] == "wide"
+long_ = len(sys.argv) > 3 and sys.argv[3] == "long"
 RAW = (b"\xff", b"\xc3", b"\xe2\x82\xac", b"\xf0\x9f\x98\x80", b"\xe2\x82", b"\x80")
 runs = docs_checked = 0
 for seed in range(first, first + n_auto):
     rng = np.random.default_rng(seed)
     arcs = craft.random_automaton(rng, 24) if wide else craft.random_automaton(rng)
     docs = craft.random_documents(rng, 160, 400, RAW) if wide else craft.random_documents(rng)
+    if long_:
+        docs = docs + [b"".join(docs[int(i)] for i in rng.integers(0, len(docs), size=int(k))) for k in (1200, 2500, 5000, 9000)]
     text, off = corpus.concat_docs(docs)
     for kind in ("matok", "datok"):
         blob = getattr(craft, kind + "_from")(arcs)
