@@ -21,13 +21,14 @@
 #define DTK_SYM_CLS_SHIFT 14
 #define DTK_SYM_WIDTH(e) (((uint32_t)(e) >> DTK_SYM_W_SHIFT) & 7u)
 #define DTK_SYM_IS_START(e) (DTK_SYM_WIDTH(e) != 0u)
-// the walks' per-lane window of the symbol stream in LDS: entries, and u16 per row (72 B)
+// the general walk's per-lane window of the symbol stream in LDS: entries, and u16 per row (72 B)
 #define DTK_WIN 32u
 #define DTK_WIN_ROW 36u
 // ---- the stream in memory: one BYTE per input byte where the model's entries fit a code table (DtkSigmaDev::n_codes:
 // the shipped models have some 170 symbols and 200 distinct entries), else the 16-bit entries themselves.  A code
 // is an index into `lut` (256 entries); DTK_SYM_CONT = no rune starts here.  Half the stream's traffic -- it was 44 %
-// of what a batch moves -- and a window of twice the positions in the same LDS (the lean walk keeps codes in its rows).
+// of what a batch moves -- and the lean walk's windows (codes) in 40 instead of 72 bytes of LDS per lane.  The code of a
+// byte below 128 is the byte itself (upload() in dtk_host.cpp; k_symbolize copies those).
 #define DTK_SYM_CONT 0xFFu
 #ifndef DTK_WIN8
 #define DTK_WIN8 32u  // positions in a lean-walk row of codes (a multiple of 16; the row has 8 bytes more: 40 B)
