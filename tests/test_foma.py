@@ -145,7 +145,8 @@ def test_product_double_array_of_simpletok_is_the_reference_kat():
     at, mine = _pairs(raw)
     at2, theirs = _pairs(shipped)
     assert at == at2 and raw[:at] == shipped[:at]            # magic, header, sigma, 'T'
-    # the only freedom: which of the two arcs into state "8 or 9" is the representative (symbols 8 and 9 of state 1)
+    # the only freedom: which of the three arcs of state 1 into one state (symbols 8, 9, 10) is its representative --
+    # ascending order picks 8, the run that wrote the shipped file picked 9
     differ = np.flatnonzero((mine != theirs).any(axis=1)).tolist()
     assert differ == [2, 8, 9, 10, 18, 19, 20], differ
     swap = {8: 9, 9: 8}
