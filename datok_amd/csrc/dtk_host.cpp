@@ -805,6 +805,7 @@ extern "C" int dtk_foma_to_datok(const void *gz_bytes, size_t n, void **out, siz
     A.clear();
     for (auto &e : net.arcs[s]) A.push_back(e.first);
     std::sort(A.begin(), A.end());
+    if (!A.empty() && (A.front() < 1 || (uint32_t)A.back() > final_)) return DTK_E_MODEL;  // (a sigma block behind the states)
     // xCheckSkipNiu, datok.go:385-406
     uint32_t base = 1;
     if (A.size() >= 3) base = (uint32_t)std::fabs((double)(max_size - 1) * .9) + 1;

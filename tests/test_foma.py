@@ -204,3 +204,17 @@ def test_product_double_array_walks_like_the_matrix_of_the_same_net(stem):
         for d in docs + [b"Erste.\n\n\n\n\x04\nN\xc3\xa4chst.\x04", b"a\x04b. c\x04\x04\nd"]:
             for flags in (3, 15, 31):
                 assert da.transduce(d, flags) == shipped.transduce(d, flags), (d[:60], flags)
+
+
+def test_product_double_array_rejects_a_net_whose_symbols_exceed_the_final_symbol():
+    """The final symbol is numbered when `##states##` is read (fomafile.go:116-121): a net whose sigma block follows its
+    states would have symbols beyond it -- the layout's slots are sized by it.  Rejected, not laid out."""
+    import datok_amd
+    from datok_amd._lib import DatokGpuError
+    raw = gzip.decompress(_read("simpletok.fst")).decode()
+    head, rest = raw.split("##sigma##\n", 1)
+    sigma, states = rest.split("##states##\n", 1)
+    states, end = states.split("##end##", 1)
+    bad = head + "##states##\n" + states + "##sigma##\n" + sigma + "##end##" + end
+    with pytest.raises(DatokGpuError):
+        datok_amd.foma_to_datok(gzip.compress(bad.encode()))
