@@ -57,11 +57,20 @@ def parse():
     return ap.parse_args()
 
 
-def walk_kernel_name(total_bytes):
+def walk_kernel_name(info, chunked):
     """The dominant kernel as rocprofv3 prints it: start record + chunk walk in one launch (k_spec_both) unless
-    DATOK_SPLIT_START=1."""
+    DATOK_SPLIT_START=1; the transition type and the EOT rules follow the model (dtk_model_info)."""
     base = "k_spec_walk" if os.environ.get("DATOK_SPLIT_START", "0") not in ("", "0") else "k_spec_both"
-    return base + "<%s, true>"
+    if not chunked:
+        base = "k_walk_doc"
+    is_da = info["kind"] == 1
+    if is_da and not info["dense_states"]:
+        trans = "DaTrans"
+    elif info["entry_bytes"] == 4 and (info["dense_states"] or info["state_count"] < 32767):
+        trans = "MatrixLeanTrans" if not info["unknown_used"] and info["stream_codes"] else "MatrixFusedTrans"
+    else:
+        trans = "MatrixTrans<u%d>" % (8 * info["entry_bytes"])
+    return "%s<%s, %s>" % (base, trans, "false" if is_da else "true")
 
 
 def timed_steps(batches, tok, steps, barrier):
@@ -351,7 +360,7 @@ def main():
                     if world == 1 else
                     "tokenizer_de.matok, one shard of the 10 GiB corpus per GPU: %d docs x %d B (BASELINE.json configs[4])")
         out = {
-            "metric": "input MB/s tokenized, tokenizer_de.matok",
+            "metric": "input MB/s tokenized, %s" % os.path.basename(args.model),
             "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u32 table cells, u8 symbol codes", "data": "synthetic",
@@ -362,10 +371,7 @@ def main():
                        "inputs": "one per batch in flight (generator seeds %s on rank 0)" % ", ".join(map(str, seeds)),
                        "step": "dtk_batch_run + dtk_batch_totals (speculation check, repairs, capacity check) per batch"},
             "roofline": {"bound": "hbm",
-                         "kernel": (walk_kernel_name(total) if tot["chunk_bytes"] else "k_walk_doc<%s, true>") % (
-                             ("MatrixLeanTrans" if not tok.info["unknown_used"] else "MatrixFusedTrans")
-                             if tok.info["entry_bytes"] == 4 and tok.info["state_count"] < 32767
-                             else "MatrixTrans<u%d>" % (8 * tok.info["entry_bytes"])),
+                         "kernel": walk_kernel_name(tok.info, bool(tot["chunk_bytes"])),
                          "achieved": round(achieved, 2),
                          "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 6),
                          "traffic": traffic, "algorithmic_bytes": int(b_alg),
