@@ -137,8 +137,7 @@ def docs_of(gen, n_docs, **kw):
     return [b[int(off[i]):int(off[i + 1])].decode("utf-8") for i in range(n_docs)]
 
 
-SAMPLE = open(os.path.join(ROOT, "datok_amd", "csrc", "dtk_sample.txt"), encoding="utf-8").read() \
-    if os.path.exists(os.path.join(ROOT, "datok_amd", "csrc", "dtk_sample.txt")) else None
+SAMPLE = None
 
 
 def main():
