@@ -26,7 +26,7 @@ EXPORTS = [
     "dtk_foma_to_matok", "dtk_foma_to_datok", "dtk_transduce_replay", "dtk_batch_render_device", "dtk_batch_render_host",
     "dtk_batch_status_host", "dtk_transduce_release", "dtk_transduce_result",
     "dtk_pipeline_create", "dtk_pipeline_free", "dtk_pipeline_set_chunking", "dtk_pipeline_run",
-    "dtk_pinned_alloc", "dtk_pinned_free", "dtk_model_hot_stats",
+    "dtk_pinned_alloc", "dtk_pinned_free",
 ]
 
 
@@ -38,12 +38,6 @@ class ModelInfo(C.Structure):
                 ("entry_bytes", C.c_uint32), ("device_bytes", C.c_uint64),
                 ("unknown_used", C.c_uint32), ("dense_states", C.c_uint32),
                 ("stream_codes", C.c_uint32)]
-
-
-class HotStats(C.Structure):
-    _fields_ = [("enabled", C.c_uint32), ("generations", C.c_uint32), ("cached_cells", C.c_uint32),
-                ("capacity", C.c_uint32), ("known_cells", C.c_uint32), ("settled", C.c_uint32),
-                ("last_miss_rate", C.c_float)]
 
 
 class Totals(C.Structure):
@@ -118,7 +112,6 @@ def lib():
     L.dtk_model_type.restype = C.c_char_p
     L.dtk_model_type.argtypes = [vp]
     L.dtk_model_get_info.argtypes = [vp, C.POINTER(ModelInfo)]
-    L.dtk_model_hot_stats.argtypes = [vp, C.POINTER(HotStats)]
     L.dtk_batch_create.argtypes = [u64, u32, C.POINTER(vp)]
     L.dtk_batch_free.argtypes = [vp]
     L.dtk_batch_free.restype = None

@@ -9,10 +9,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <mutex>
 #include <string>
 #include <string_view>
-#include <unordered_map>
 #include <vector>
 
 #include "../../include/datok_gpu.h"
@@ -85,29 +83,6 @@ struct dtk_model {
   void *d_codes = nullptr;  // code_entry [256] u16, code_lt256 [256] u8, code_runes [n_runes] u8
   DtkTableDev tab{};
   DtkSigmaDev sig{};
-  struct HotCache *hot = nullptr;  // the lean walk's hot cells (below); null: the model's walk has no use for them
-};
-
-// ---- the hot cells of a model (dtk_internal.h, DtkHotDev) ----
-// Which cells are hot depends on the text, so the model learns them from it: the first-pass walk of a batch logs a
-// sample of the lookups its LDS cache could not answer, dtk_batch_totals & co. hand the log over, and the keys that
-// miss most often -- together with what is cached already -- are laid out as the next generation of the table
-// (two {key, cell} pairs per bucket, the hotter keys first; the hash multiplier with the least loss of a few).  A run
-// that misses little settles the cache; every 64th run looks again.  Generations stay allocated until the model is
-// freed: batches in flight on other streams may still read an older one.  Nothing here affects results -- a key is
-// compared before its cell is used, and the cell is a copy of the table's.
-struct HotCache {
-  std::mutex mu;
-  std::vector<uint32_t> cells;   // host copy of the device table (the values the cache holds)
-  struct Gen { uint32_t *d_buckets; uint32_t mul; };
-  std::vector<Gen> gens;         // gens.back() is current
-  std::unordered_map<uint32_t, float> rate;  // key -> misses per lookup when last seen uncached
-  std::vector<uint32_t> cached;  // keys of the current generation
-  uint64_t runs = 0;             // first-pass walks launched with this model
-  bool settled = false;
-  float last_miss_rate = -1.0f;  // of the last logged run (share of the lookups that went to the table)
-  float gen_miss_rate = 2.0f;    // ... of the run the current generation was built from
-  static constexpr size_t MAX_GENS = 24;
 };
 
 // Go unicode/utf8.DecodeRune (host copy, used for the sigma block of the model
@@ -273,94 +248,6 @@ static int upload(dtk_model *m, const void *tab, size_t tab_bytes) {
   return DTK_OK;
 }
 
-// The next generation of the hot cells: every key the model knows a rate for, hottest first, into its bucket while
-// the bucket has room.
-static int hot_rebuild(HotCache *h) {
-  std::vector<std::pair<float, uint32_t>> cand;
-  cand.reserve(h->rate.size());
-  for (const auto &kv : h->rate)
-    if (kv.first < h->cells.size()) cand.emplace_back(kv.second, kv.first);
-  std::sort(cand.begin(), cand.end(), [](const auto &a, const auto &b) { return a.first != b.first ? a.first > b.first : a.second < b.second; });
-  if (cand.size() > 2u * DTK_HOT_BUCKETS) cand.resize(2u * DTK_HOT_BUCKETS);  // (more cannot fit)
-  static const uint32_t muls[] = {0x9E3779u, 0x7F4A7Cu, 0xC2B2AEu, 0x85EBCAu, 0x27D4EBu, 0x165667u, 0xD6E8FFu, 0x5BD1E9u};
-  uint32_t best_mul = muls[0];
-  double best_lost = 1e300;
-  std::vector<uint8_t> fill(DTK_HOT_BUCKETS);
-  for (uint32_t mul : muls) {
-    std::fill(fill.begin(), fill.end(), 0);
-    double lost = 0;
-    for (const auto &c : cand) {
-      uint8_t &f = fill[dtk_hot_bucket(c.second, mul)];
-      if (f < 2) f++; else lost += c.first;
-    }
-    if (lost < best_lost) { best_lost = lost; best_mul = mul; }
-  }
-  std::vector<uint32_t> img(4u * DTK_HOT_BUCKETS, DTK_HOT_EMPTY);
-  std::fill(fill.begin(), fill.end(), 0);
-  h->cached.clear();
-  for (const auto &c : cand) {
-    const uint32_t bkt = dtk_hot_bucket(c.second, best_mul);
-    if (fill[bkt] >= 2) continue;
-    img[4u * bkt + 2u * fill[bkt]] = c.second;
-    img[4u * bkt + 2u * fill[bkt] + 1u] = h->cells[c.second];
-    fill[bkt]++;
-    h->cached.push_back(c.second);
-  }
-  HotCache::Gen g{nullptr, best_mul};
-  HIP_TRY(hipMalloc((void **)&g.d_buckets, img.size() * 4));
-  HIP_TRY(hipMemcpy(g.d_buckets, img.data(), img.size() * 4, hipMemcpyHostToDevice));
-  h->gens.push_back(g);
-  return DTK_OK;
-}
-
-// What a first-pass walk of this model should use: the current generation, and whether the run should log.
-// Returns the generation's number (for hot_learn).
-static size_t hot_current(const dtk_model *m, DtkHotDev *out, bool *log) {
-  HotCache *h = m->hot;
-  std::lock_guard<std::mutex> lk(h->mu);
-  const HotCache::Gen &g = h->gens.back();
-  out->buckets = g.d_buckets; out->mul = g.mul; out->log = nullptr; out->log_every = 1;
-  *log = !h->settled || (h->runs & 63u) == 63u;
-  h->runs++;
-  return h->gens.size() - 1;
-}
-
-// The log of one run: n_stored keys (of n_logged the walk tried to log, a sixteenth of the logging blocks' misses;
-// those blocks made `seen` lookups), taken against generation `gen`.
-static int hot_learn(const dtk_model *m, const uint32_t *keys, uint32_t n_stored, uint32_t n_logged, uint64_t seen, size_t gen) {
-  HotCache *h = m->hot;
-  std::lock_guard<std::mutex> lk(h->mu);
-  if (gen + 1 != h->gens.size() || seen == 0) return DTK_OK;  // measured against an older table: says nothing about this one
-  const float miss_rate = std::min(1.0f, 16.0f * (float)n_logged / (float)seen);
-  h->last_miss_rate = miss_rate;
-  if (n_stored) {
-    std::unordered_map<uint32_t, uint32_t> cnt;
-    for (uint32_t i = 0; i < n_stored; i++) cnt[keys[i]]++;
-    for (const auto &kv : cnt) {
-      const float r = miss_rate * (float)kv.second / (float)n_stored;
-      auto it = h->rate.find(kv.first);
-      if (it == h->rate.end()) h->rate.emplace(kv.first, r); else it->second = 0.5f * (it->second + r);
-    }
-    if (h->rate.size() > 16u * DTK_HOT_BUCKETS) {  // forget the coldest
-      std::vector<float> v;
-      v.reserve(h->rate.size());
-      for (const auto &kv : h->rate) v.push_back(kv.second);
-      std::nth_element(v.begin(), v.begin() + 8u * DTK_HOT_BUCKETS, v.end(), std::greater<float>());
-      const float cut = v[8u * DTK_HOT_BUCKETS];
-      for (auto it = h->rate.begin(); it != h->rate.end();) it = it->second < cut ? h->rate.erase(it) : std::next(it);
-    }
-  }
-  // Little left to gain, or no generations left: the cache stays as it is (every 64th run looks again).
-  // (... or the last generation gained nothing: a text whose hot cells do not fit)
-  if (miss_rate < 0.004f || miss_rate > 0.85f * h->gen_miss_rate || h->gens.size() >= HotCache::MAX_GENS) {
-    h->settled = true;
-    return DTK_OK;
-  }
-  h->settled = false;
-  h->gen_miss_rate = miss_rate;
-  return hot_rebuild(h);
-}
-
 static bool special_ids_ok(const dtk_model *m) {
   // The walk compares symbols against these ids; the symbol stream has 11 bits.
   // identity == unknown makes the retry of matrix.go:478-485 spin forever upstream.
@@ -506,15 +393,7 @@ static int layout_matrix(dtk_model *m, const std::vector<uint32_t> &arr, uint64_
   m->tab.n_states = (uint32_t)N;
   m->tab.n_eps = m->n_eps_states;
   m->tab.start = newid[1];
-  int rc = upload(m, host.data(), host.size());
-  if (rc != DTK_OK) return rc;
-  // the lean walk applies (with_trans, dtk_kernels.hip): its first pass keeps the model's hot cells in LDS
-  if (fused && m->tab.ident_guard == 0xFFFFFFFFu && !m->tab.plain_walk && m->sig.n_codes && !(getenv("DATOK_NO_HOT") && atoi(getenv("DATOK_NO_HOT")) != 0)) {
-    m->hot = new HotCache();
-    m->hot->cells.assign(reinterpret_cast<const uint32_t *>(host.data()), reinterpret_cast<const uint32_t *>(host.data()) + cells_total);
-    rc = hot_rebuild(m->hot);  // (an empty first generation: the first batches' logs fill it)
-  }
-  return rc;
+  return upload(m, host.data(), host.size());
 }
 
 // ParseDatok (datok.go:621-729) + device layout.
@@ -1028,27 +907,7 @@ extern "C" void dtk_model_free(dtk_model *m) {
   if (m->d_runes) (void)hipFree(m->d_runes);
   if (m->d_syms) (void)hipFree(m->d_syms);
   if (m->d_codes) (void)hipFree(m->d_codes);
-  if (m->hot) {
-    for (auto &g : m->hot->gens)
-      if (g.d_buckets) (void)hipFree(g.d_buckets);
-    delete m->hot;
-  }
   delete m;
-}
-
-extern "C" int dtk_model_hot_stats(const dtk_model *m, dtk_hot_stats *o) {
-  if (!m || !o) return DTK_E_ARG;
-  memset(o, 0, sizeof(*o));
-  if (!m->hot) return DTK_OK;
-  std::lock_guard<std::mutex> lk(m->hot->mu);
-  o->enabled = 1;
-  o->generations = (uint32_t)m->hot->gens.size();
-  o->cached_cells = (uint32_t)m->hot->cached.size();
-  o->capacity = 2u * DTK_HOT_BUCKETS;
-  o->known_cells = (uint32_t)m->hot->rate.size();
-  o->settled = m->hot->settled ? 1u : 0u;
-  o->last_miss_rate = m->hot->last_miss_rate;
-  return DTK_OK;
 }
 
 extern "C" const char *dtk_model_type(const dtk_model *m) {
@@ -1114,10 +973,6 @@ struct dtk_batch {
   DtkLaneState *d_lane_start = nullptr, *d_lane_end = nullptr;
   DtkLanePlan *d_lane_plan = nullptr;
   uint32_t repair_rounds = 0;        // of the last run
-  uint32_t *d_hot_log = nullptr;     // the walk's log of hot-cell misses (DtkHotDev::log), if the last run kept one
-  bool hot_logged = false;
-  size_t hot_gen = 0;                // generation of the model's hot cells the last run used
-  uint32_t *h_hot_log = nullptr;     // pinned: [0..1] the log's counters
   const dtk_model *last_model = nullptr;
   uint32_t last_flags = 0;
   uint64_t *d_tok_off = nullptr, *d_sent_off = nullptr, *d_text_off = nullptr;
@@ -1243,8 +1098,6 @@ extern "C" int dtk_batch_create(uint64_t max_bytes, uint32_t max_docs, dtk_batch
   // [0..15] device totals ([10] doubles as the render size), [16..] the striped lookup counters
   B_TRY(hipHostMalloc((void **)&b->h_totals, DTK_TOTALS_BYTES, hipHostMallocDefault));
   B_TRY(hipHostMalloc((void **)&b->h_off_pin, ((uint64_t)max_docs + 1) * 8, hipHostMallocDefault));
-  B_TRY(hipMalloc((void **)&b->d_hot_log, (2ull + DTK_HOT_LOG_CAP) * 4));
-  B_TRY(hipHostMalloc((void **)&b->h_hot_log, 16, hipHostMallocDefault));
 #undef B_TRY
   // typical German: 0.18 tokens and 0.06 sentence ints per byte; grown on demand
   int rc = alloc_outputs(b, max_bytes / 3 + max_docs + 16, max_bytes / 8 + 2ull * max_docs + 16,
@@ -1264,12 +1117,11 @@ extern "C" void dtk_batch_free(dtk_batch *b) {
                   b->d_sent_off, b->d_text_off, b->d_rstart, b->d_rend, b->d_sent,
                   b->d_bstart, b->d_bend, b->d_ttok, b->d_tsent,
                   b->d_sbefore, b->d_ts_end, b->d_doc_ns, b->d_scan_ws, b->d_rws, b->d_out_off, b->d_out,
-                  b->d_exact_ids, b->d_exact_cnt, b->d_exact_off, b->d_calls, b->d_hot_log};
+                  b->d_exact_ids, b->d_exact_cnt, b->d_exact_off, b->d_calls};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (b->h_totals) (void)hipHostFree(b->h_totals);
   if (b->h_off_pin) (void)hipHostFree(b->h_off_pin);
-  if (b->h_hot_log) (void)hipHostFree(b->h_hot_log);
   for (hipEvent_t e : b->ev)
     if (e) (void)hipEventDestroy(e);
   if (b->stream) (void)hipStreamDestroy(b->stream);
@@ -1615,23 +1467,11 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
     STAGE(5); STAGE(6); STAGE(7);
   } else {
     DtkSpecArgs sp = spec_args(b, false);
+    sp_first = sp;
     uint32_t *nb = (uint32_t *)(b->d_totals + 8);  // nb[0]: broken documents after the first pass, nb[r + 1]: after round r
     // DATOK_SPLIT_START=1: start records and chunk walk as two launches (the repair rounds' kernels)
     static const bool split_env = getenv("DATOK_SPLIT_START") && atoi(getenv("DATOK_SPLIT_START")) != 0;
     const bool split = split_env || sp.lds_words == 0;  // (k_spec_both reports through the wave's LDS bitmaps)
-    b->hot_logged = false;
-    if (m->hot && !split) {  // the first pass keeps the model's hot cells in LDS; some runs log what it misses
-      bool log = false;
-      b->hot_gen = hot_current(m, &sp.hot, &log);
-      if (log) {
-        HIP_TRY(hipMemsetAsync(b->d_hot_log, 0, 8, s));
-        sp.hot.log = b->d_hot_log;
-        const uint32_t blocks = (b->n_lanes + 64u * DTK_HOT_WPB - 1u) / (64u * DTK_HOT_WPB);
-        sp.hot.log_every = std::max(1u, blocks / 32u);
-        b->hot_logged = true;
-      }
-    }
-    sp_first = sp;
     // Device-side repair: if the batch's last run had to repair (text with tags, say), two repair rounds are
     // enqueued right behind the first pass; their kernels return at once when the verification before them found
     // nothing broken, and the scan / compaction behind them only run once nothing is.  A miss then costs no host
@@ -1678,7 +1518,6 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
   STAGE(9);
 #undef STAGE
   HIP_TRY(hipMemcpyAsync(b->h_totals, b->d_totals, DTK_TOTALS_BYTES, hipMemcpyDeviceToHost, s));
-  if (b->hot_logged) HIP_TRY(hipMemcpyAsync(b->h_hot_log, b->d_hot_log, 8, hipMemcpyDeviceToHost, s));
   b->ran = true;
   b->totals_valid = false;
   b->render_flags = 0xFFFFFFFFu;
@@ -1777,14 +1616,6 @@ static int finish(dtk_batch *b) {
   if (!b->ran) return DTK_E_STATE;
   if (b->totals_valid) return DTK_OK;
   HIP_TRY(hipStreamSynchronize(b->stream));
-  if (b->hot_logged) {  // what the first pass's cache of hot cells missed: the model learns from it
-    b->hot_logged = false;
-    const uint32_t n_logged = b->h_hot_log[0], n_stored = std::min(n_logged, DTK_HOT_LOG_CAP);
-    std::vector<uint32_t> keys(n_stored);
-    if (n_stored) HIP_TRY(hipMemcpy(keys.data(), b->d_hot_log + 2, (size_t)n_stored * 4, hipMemcpyDeviceToHost));
-    int rc = hot_learn(b->last_model, keys.data(), n_stored, n_logged, b->h_hot_log[1], b->hot_gen);
-    if (rc != DTK_OK) return rc;
-  }
   // Speculation check failed somewhere: those documents are repaired from the last owning lane before their first
   // bad lane on (fix records, clear, re-link, re-walk, re-verify) until every lane chains.  Rounds enqueued ahead of
   // time (dtk_batch_run) have run on the device already; what is still broken behind them is repaired from here,

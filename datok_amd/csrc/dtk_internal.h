@@ -132,35 +132,6 @@ struct DtkTableDev {
   uint32_t epsilon, unknown, identity;
 };
 
-// ---- hot cells in LDS (the lean walk, first pass).  The walk of real text asks a table of millions of cells for a
-// couple of thousand of them (tokenizer_de on German: 1 800-4 300 distinct cells per 150 000 lookups, 2.6 per visited
-// state; the top 1 024 answer 93-98 % of the lookups) -- as a gather in which every lane touches another cache line,
-// one address cycle per lane in the CU's L1.  A block of DTK_HOT_WPB waves therefore keeps a cache of hot cells in
-// LDS: DTK_HOT_BUCKETS buckets of two {key, cell} pairs (key = index of the cell in the table), the bucket picked by
-// a multiplicative hash of the key; a lane that finds its key takes the cell from there, the others load it from
-// the table as before (exec-masked: a gather of a few lanes costs a few address cycles).  The cache is exact (keys
-// are compared), so its content only affects speed: the model learns it from a sampled log of the misses (dtk_host.cpp,
-// HotCache).
-#ifndef DTK_HOT_BUCKETS
-#define DTK_HOT_BUCKETS 2048u  // x 16 B = 32 KB per block (a power of two)
-#endif
-#ifndef DTK_HOT_WPB
-#define DTK_HOT_WPB 8u         // waves per block of the first-pass walk
-#endif
-#define DTK_HOT_EMPTY 0xFFFFFFFFu
-#define DTK_HOT_LOG_CAP 32768u // keys a run can log
-struct DtkHotDev {
-  const uint32_t *buckets;  // [DTK_HOT_BUCKETS][4] {key0, cell0, key1, cell1}, or null: no cache (one wave per block)
-  uint32_t mul;             // bucket = (umul24(key, mul) >> 21) & (DTK_HOT_BUCKETS - 1)
-  uint32_t *log;            // [0] keys logged, [1] lookups seen by the logging blocks, [2 ..] keys; null: no log
-  uint32_t log_every;       // blocks b with b % log_every == 0 log (a sixteenth of their misses)
-};
-#ifdef __cplusplus
-static inline uint32_t dtk_hot_bucket(uint32_t key, uint32_t mul) {
-  return (((key & 0xFFFFFFu) * (mul & 0xFFFFFFu)) >> 21) & (DTK_HOT_BUCKETS - 1u);
-}
-#endif
-
 // ---- speculative chunk lanes
 #define LANE_F_SENT 1u     // sentenceEnd (matrix.go:360)
 #define LANE_F_TEXT 2u     // textEnd (matrix.go:363)
@@ -212,7 +183,6 @@ struct DtkSpecArgs {
   // A repair round enqueued ahead of time (device-side repair): its kernels return at once unless *go != 0
   // (the number of documents the previous verification found broken); null: run.
   const uint32_t *go;
-  struct DtkHotDev hot;             // first pass of the lean walk: the hot cells (dtk_launch_spec stage 6)
 };
 
 struct DtkWalkArgs {

@@ -595,19 +595,16 @@ struct EventSink {
 };
 
 // the wave's LDS bitmaps: cleared before the lanes walk, OR-ed into memory afterwards (all 64 lanes take part;
-// every wave of a block has its own set, LDS operations of a wave complete in order)
+// one wave per block, LDS operations of a wave complete in order)
 __device__ __forceinline__ void lds_bits_clear(uint32_t *lds_, uint32_t lw) {
   dtk_lds_u32 *lds = (dtk_lds_u32 *)lds_;
-  for (uint32_t j = lane_id(); j < 3u * lw; j += WAVE) lds[j] = 0u;
-  // (the bitmaps are the wave's own: LDS operations of one wave complete in order, no block barrier)
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
+  for (uint32_t j = threadIdx.x; j < 3u * lw; j += WAVE) lds[j] = 0u;
+  __syncthreads();
 }
 __device__ __forceinline__ void lds_bits_flush(const uint32_t *lds_, uint32_t lw, uint32_t *g, uint32_t gw, uint32_t w0) {
   const dtk_lds_u32 *lds = (const dtk_lds_u32 *)lds_;
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  for (uint32_t j = lane_id(); j < lw; j += WAVE) {
+  __syncthreads();
+  for (uint32_t j = threadIdx.x; j < lw; j += WAVE) {
     if (w0 + j >= gw) break;
 #pragma unroll
     for (uint32_t k = 0; k < 3u; k++) {
@@ -922,21 +919,12 @@ extern "C" int dtk_probe_read(unsigned long long *out, int reset) {
 }
 #endif
 
-// The block's cache of hot cells (dtk_internal.h, DtkHotDev): `b` points at its DTK_HOT_BUCKETS buckets in LDS.
-typedef uint32_t dtk_u32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) dtk_u32x4 dtk_lds_u4;
-struct HotLds {
-  const dtk_lds_u4 *b;
-  uint32_t mul;
-  uint32_t *log;  // this block logs a sample of its misses (null: not)
-};
-
-template <int MODE, bool FIRST = false, bool IS_MATRIX = true, bool HOT = false>
+template <int MODE, bool FIRST = false, bool IS_MATRIX = true>
 __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const DtkSym &sym,
                                            uint64_t off, uint32_t len, DtkLaneState init, uint32_t stop_pos,
                                            EventSink &sink, uint32_t epsilon, uint32_t cap, DtkLaneState &fin,
                                            uint32_t &st_out, uint32_t &steps_out, uint16_t *win_row,
-                                           const uint16_t *lut, const HotLds &hot = HotLds{}) {
+                                           const uint16_t *lut) {
   const DtkSymAt s{sym, off};
   const uint32_t *__restrict__ tab = tr.tab;
   const uint32_t stride = tr.stride, n_eps = tr.n_eps;
@@ -1054,26 +1042,7 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const Dtk
     const uint32_t p_n = backtrack ? eps_p : (advance ? pn : p);
     // right after a backtrack the bare epsilon symbol: width 0, that iteration consumes nothing (matrix.go:487-497)
     const uint32_t e_n = backtrack ? epsilon : en;
-    uint32_t x_n;
-    if constexpr (HOT) {
-      // the block's cache of hot cells first: the bucket of the cell's index, both of its pairs in one 16-byte read;
-      // only the lanes that find neither key ask the table (a gather of a few lanes instead of 64)
-      const uint32_t i_n = __umul24(t_n, stride) + (e_n & DTK_SYM_MASK);
-      const uint32_t ha = (__umul24(i_n, hot.mul) >> 17) & ((DTK_HOT_BUCKETS - 1u) << 4);
-      const dtk_u32x4 kv = *reinterpret_cast<const dtk_lds_u4 *>(reinterpret_cast<const __attribute__((address_space(3))) char *>(hot.b) + ha);
-      const bool h0 = kv.x == i_n, h1 = kv.z == i_n;
-      x_n = h0 ? kv.y : kv.w;
-      if (!(h0 | h1)) {
-        x_n = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(tab) + (i_n << 2));
-        // a sixteenth of the logging blocks' misses, spread over the walk: what the model learns the cache from
-        if (hot.log && ((budget ^ threadIdx.x) & 15u) == 0u) {
-          const uint32_t n_ = atomicAdd(hot.log, 1u);
-          if (n_ < DTK_HOT_LOG_CAP) hot.log[2u + n_] = i_n;
-        }
-      }
-    } else {
-      x_n = DTK_TAB(t_n, e_n);
-    }
+    const uint32_t x_n = DTK_TAB(t_n, e_n);
     // nontoken && (comp || (advance && p == tp)), matrix.go:584-588.  (As lane masks combined in scalar registers,
     //  and here, in the block of the comparisons: written with && / || or & / | further down the compiler builds
     //  the predicate from 0/1 integers in vector registers, seven instructions instead of two.)
@@ -1245,14 +1214,14 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const Dtk
 }
 
 // the lean walk: fused cells and no arc on `unknown` (MatrixLeanTrans, picked by the launcher)
-template <typename TRANS, bool IS_MATRIX, int MODE, bool FIRST = false, bool HOT = false>
+template <typename TRANS, bool IS_MATRIX, int MODE, bool FIRST = false>
 __device__ __forceinline__ void walk_any(const TRANS &tr, const DtkSym &sym, uint64_t off,
                                          uint32_t len, DtkLaneState init, uint32_t stop_pos, EventSink &sink,
                                          uint32_t epsilon, uint32_t unknown, uint32_t identity, uint32_t cap,
                                          DtkLaneState &fin, uint32_t &st_out, uint32_t &steps_out,
-                                         uint16_t *win_row, const uint16_t *lut, const HotLds &hot = HotLds{}) {
+                                         uint16_t *win_row, const uint16_t *lut) {
   if constexpr (TRANS::LEAN)
-    walk_fused<MODE, FIRST, IS_MATRIX, HOT>(tr, sym, off, len, init, stop_pos, sink, epsilon, cap, fin, st_out, steps_out, win_row, lut, hot);
+    walk_fused<MODE, FIRST, IS_MATRIX>(tr, sym, off, len, init, stop_pos, sink, epsilon, cap, fin, st_out, steps_out, win_row, lut);
   else
     walk_lane<TRANS, IS_MATRIX, MODE>(tr, sym, off, len, init, stop_pos, sink, epsilon, unknown, identity, cap,
                                       fin, st_out, steps_out, win_row);
@@ -1263,12 +1232,11 @@ __device__ __forceinline__ uint32_t step_cap(uint32_t factor, uint32_t len) {
   return c > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)c;
 }
 
-__device__ __forceinline__ unsigned long long add_steps(unsigned long long *counter, uint32_t mine) {
+__device__ __forceinline__ void add_steps(unsigned long long *counter, uint32_t mine) {
   unsigned long long tot = mine;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) tot += __shfl_down(tot, o);
   if (lane_id() == 0 && tot) atomicAdd(counter + (blockIdx.x & (DTK_STEP_STRIPES - 1u)) * 16u, tot);  // see DTK_STEP_STRIPES
-  return tot;  // (lane 0: the wave's lookups)
 }
 
 // ---- the exact pass: one lane per irregular document ----
@@ -1364,17 +1332,16 @@ struct ExactSink {
   __device__ __forceinline__ void out_of_order() {}  // (call order is what this sink records)
 };
 
-// the lanes' windows of the symbol stream and, for the lean loop, the model's code table (WPB_ waves per block)
-#define DTK_WINDOWS_N(TRANS, SYM, WPB_)                                                               \
+// the lanes' windows of the symbol stream and, for the lean loop, the model's code table (one wave per block)
+#define DTK_WINDOWS(TRANS, SYM)                                                                       \
   constexpr uint32_t WIN_ROW_ = TRANS::LEAN ? (DTK_WIN8 + 8u) / 2u : DTK_WIN_ROW;                     \
-  __shared__ uint16_t s_win[(WPB_) * WAVE * WIN_ROW_];                                                \
+  __shared__ uint16_t s_win[WAVE * WIN_ROW_];                                                         \
   __shared__ uint16_t s_lut[TRANS::LEAN ? 256 : 1];                                                   \
   uint16_t *win_row = s_win + threadIdx.x * WIN_ROW_;                                                 \
   if constexpr (TRANS::LEAN) {                                                                        \
-    for (uint32_t i_ = threadIdx.x; i_ < 256u; i_ += (WPB_) * WAVE) s_lut[i_] = (SYM).lut[i_];        \
+    for (uint32_t i_ = threadIdx.x; i_ < 256u; i_ += WAVE) s_lut[i_] = (SYM).lut[i_];                 \
     __syncthreads();                                                                                  \
   }
-#define DTK_WINDOWS(TRANS, SYM) DTK_WINDOWS_N(TRANS, SYM, 1u)
 
 template <typename TRANS, bool IS_MATRIX>
 __global__ __launch_bounds__(WAVE) void k_exact_doc(TRANS tr, DtkExactArgs X, uint32_t epsilon, uint32_t unknown,
@@ -1461,11 +1428,11 @@ extern "C" int dtk_phase_read(unsigned long long *out, int reset) {
 #endif
 
 // the start record of lane k >= 0 of document d (k_spec_start, k_spec_both)
-template <typename TRANS, bool IS_MATRIX, bool HOT = false>
+template <typename TRANS, bool IS_MATRIX>
 __device__ __forceinline__ DtkLaneState start_record(const TRANS &tr, const DtkWalkArgs &A, const DtkSpecArgs &S,
                                                      uint32_t k, uint64_t off, uint32_t len, uint32_t epsilon,
                                                      uint32_t unknown, uint32_t identity, uint16_t *win_row,
-                                                     const uint16_t *s_lut, uint32_t &steps, const HotLds &hot = HotLds{}) {
+                                                     const uint16_t *s_lut, uint32_t &steps) {
   DtkLaneState rec{0u, tr.start_state(), tr.start_aux(), 0u};
   if (k > 0) {
     const uint32_t kc = k * S.chunk;
@@ -1556,12 +1523,12 @@ __device__ __forceinline__ DtkLaneState start_record(const TRANS &tr, const DtkW
     if (sp > 0) {
       while (sp < len && !dtk_sym_is_start(A.sym, off + sp)) sp++;
       DtkLaneState init{sp, tr.start_state(), tr.start_aux(), 0u};
-      walk_any<TRANS, IS_MATRIX, MODE_START, false, HOT>(tr, A.sym, off, len, init, kc, sink, epsilon, unknown,
-                                                          identity, step_cap(A.step_factor, len), rec, st, steps, win_row, s_lut, hot);
+      walk_any<TRANS, IS_MATRIX, MODE_START>(tr, A.sym, off, len, init, kc, sink, epsilon, unknown,
+                                              identity, step_cap(A.step_factor, len), rec, st, steps, win_row, s_lut);
     } else {
       // sp == 0: the walk from the true initial state; its first sync point at/after kc
-      walk_any<TRANS, IS_MATRIX, MODE_START, false, HOT>(tr, A.sym, off, len, rec, kc, sink, epsilon, unknown,
-                                                          identity, step_cap(A.step_factor, len), rec, st, steps, win_row, s_lut, hot);
+      walk_any<TRANS, IS_MATRIX, MODE_START>(tr, A.sym, off, len, rec, kc, sink, epsilon, unknown,
+                                              identity, step_cap(A.step_factor, len), rec, st, steps, win_row, s_lut);
     }
   }
   return rec;
@@ -1590,32 +1557,19 @@ __global__ __launch_bounds__(WAVE) void k_spec_start(TRANS tr, DtkWalkArgs A, Dt
 // with a record walks; what lanes behind a broken chain stored is cleared by the repair round.
 extern __shared__ uint32_t s_dyn_bits[];  // the wave's event bitmaps (3 kinds x S.lds_words), if any
 
-// WPB waves per block; HOT: the block keeps the model's hot cells in LDS (DtkHotDev; the lean loop only).
-template <typename TRANS, bool IS_MATRIX, uint32_t WPB, bool HOT>
-__global__ __launch_bounds__(WAVE * WPB) void k_spec_both(TRANS tr, DtkWalkArgs A, DtkSpecArgs S,
-                                                          uint32_t epsilon, uint32_t unknown,
-                                                          uint32_t identity) {
-  DTK_WINDOWS_N(TRANS, A.sym, WPB)
-  __shared__ dtk_u32x4 s_hot[HOT ? DTK_HOT_BUCKETS : 1u];
-  HotLds hot{};
-  if constexpr (HOT) {
-    const dtk_u32x4 *__restrict__ g = reinterpret_cast<const dtk_u32x4 *>(S.hot.buckets);
-    for (uint32_t i = threadIdx.x; i < DTK_HOT_BUCKETS; i += WAVE * WPB) s_hot[i] = g[i];
-    __syncthreads();
-    hot.b = (const dtk_lds_u4 *)s_hot; hot.mul = S.hot.mul;
-    hot.log = (S.hot.log && blockIdx.x % S.hot.log_every == 0u) ? S.hot.log : nullptr;
-  }
-  const uint32_t wid = threadIdx.x >> 6;
-  const uint32_t W0 = (blockIdx.x * WPB + wid) * WAVE;  // the wave's first lane
-  const bool wave_live = W0 < S.n_lanes;
-  uint32_t *lds_bits = S.lds_words ? s_dyn_bits + wid * 3u * S.lds_words : nullptr;
+template <typename TRANS, bool IS_MATRIX>
+__global__ __launch_bounds__(WAVE) void k_spec_both(TRANS tr, DtkWalkArgs A, DtkSpecArgs S,
+                                                    uint32_t epsilon, uint32_t unknown,
+                                                    uint32_t identity) {
+  DTK_WINDOWS(TRANS, A.sym)
+  uint32_t *lds_bits = S.lds_words ? s_dyn_bits : nullptr;
 #ifdef DTK_PROBE
   const unsigned long long pt0 = clock64();
   unsigned long long pt1 = pt0, pt2 = pt0;
   s_probe_mark = pt0;
 #endif
-  const uint32_t L = W0 + lane_id();
-  const uint32_t w0 = (S.lds_words && wave_live) ? lds_bits_word0(A, S, W0) : 0u;
+  const uint32_t L = blockIdx.x * WAVE + threadIdx.x;
+  const uint32_t w0 = S.lds_words ? lds_bits_word0(A, S, blockIdx.x * WAVE) : 0u;
   if (lds_bits) lds_bits_clear(lds_bits, S.lds_words);
   uint32_t steps = 0;
   if (L < S.n_lanes) {
@@ -1624,7 +1578,7 @@ __global__ __launch_bounds__(WAVE * WPB) void k_spec_both(TRANS tr, DtkWalkArgs 
     const uint64_t off = A.doc_off[d];
     const uint32_t len = (uint32_t)(A.doc_off[d + 1] - off);
     const DtkLaneState rec =
-        start_record<TRANS, IS_MATRIX, HOT>(tr, A, S, k, off, len, epsilon, unknown, identity, win_row, s_lut, steps, hot);
+        start_record<TRANS, IS_MATRIX>(tr, A, S, k, off, len, epsilon, unknown, identity, win_row, s_lut, steps);
 #ifdef DTK_PROBE
     pt1 = clock64();
 #endif
@@ -1641,8 +1595,8 @@ __global__ __launch_bounds__(WAVE * WPB) void k_spec_both(TRANS tr, DtkWalkArgs 
       EventSink sink;
       sink.init(A, off, d, rec.p, 0xFFFFFFFFu, lds_bits, S.lds_words, w0);
       uint32_t st = 0, steps2 = 0;
-      walk_any<TRANS, IS_MATRIX, MODE_CHUNK, true, HOT>(tr, A.sym, off, len, rec, stop, sink, epsilon, unknown,
-                                                         identity, step_cap(A.step_factor, len), fin, st, steps2, win_row, s_lut, hot);
+      walk_any<TRANS, IS_MATRIX, MODE_CHUNK, true>(tr, A.sym, off, len, rec, stop, sink, epsilon, unknown,
+                                                    identity, step_cap(A.step_factor, len), fin, st, steps2, win_row, s_lut);
       steps += steps2;
       if (sink.dropped) fin.flags |= LANE_F_DROPPED;
       cnt.tok = sink.c_tok; cnt.sent = sink.c_sent; cnt.text = sink.c_text; cnt.status = st | sink.st;
@@ -1654,9 +1608,8 @@ __global__ __launch_bounds__(WAVE * WPB) void k_spec_both(TRANS tr, DtkWalkArgs 
     S.lane_end[L] = fin;
     S.lane_cnt[L] = cnt;
   }
-  if (lds_bits && wave_live) lds_bits_flush(lds_bits, S.lds_words, A.bits, A.bit_words, w0);
-  const unsigned long long wave_steps = add_steps(A.steps, steps);
-  if (HOT && hot.log && lane_id() == 0 && wave_steps) atomicAdd(hot.log + 1, (uint32_t)wave_steps);  // (what the logged misses are a share of)
+  if (lds_bits) lds_bits_flush(lds_bits, S.lds_words, A.bits, A.bit_words, w0);
+  add_steps(A.steps, steps);
 #ifdef DTK_PROBE
   {
     __syncthreads();
@@ -3026,17 +2979,7 @@ extern "C" int dtk_launch_spec(const DtkTableDev *tab, const DtkWalkArgs *args, 
     case 6:  // first pass: start records and chunk walk in one launch
       return with_trans(tab, args->sym.lut != nullptr, [&](auto tr, auto is_matrix) {
         using TR = decltype(tr);
-        constexpr bool IM = decltype(is_matrix)::value;
-        if constexpr (TR::LEAN) {
-          if (spec->hot.buckets) {  // blocks of DTK_HOT_WPB waves around the model's hot cells in LDS
-            const uint32_t blocks = (lane_blocks + DTK_HOT_WPB - 1u) / DTK_HOT_WPB;
-            hipLaunchKernelGGL((k_spec_both<TR, IM, DTK_HOT_WPB, true>), dim3(blocks), dim3(WAVE * DTK_HOT_WPB),
-                               DTK_HOT_WPB * 3u * spec->lds_words * sizeof(uint32_t), s, tr, *args, *spec, tab->epsilon,
-                               tab->unknown, tab->identity);
-            return;
-          }
-        }
-        hipLaunchKernelGGL((k_spec_both<TR, IM, 1u, false>), dim3(lane_blocks), dim3(WAVE),
+        hipLaunchKernelGGL((k_spec_both<TR, decltype(is_matrix)::value>), dim3(lane_blocks), dim3(WAVE),
                            3u * spec->lds_words * sizeof(uint32_t), s, tr, *args, *spec, tab->epsilon, tab->unknown,
                            tab->identity);
       });

@@ -231,12 +231,6 @@ class Tokenizer:
         """matrix.go:102 / datok.go:252"""
         return lib().dtk_model_type(self._h).decode()
 
-    def hot_stats(self) -> dict:
-        """The walk's cache of hot table cells (dtk_model_hot_stats): speed only, never results."""
-        st = _lib.HotStats()
-        check(lib().dtk_model_hot_stats(self._h, C.byref(st)))
-        return {k: getattr(st, k) for k, _ in _lib.HotStats._fields_}
-
     def transduce(self, r, w) -> bool:
         """matrix.go:340-342: TransduceTokenWriter(r, NewTokenWriter(w, SIMPLE))."""
         return self.transduce_token_writer(r, new_token_writer(w, SIMPLE))

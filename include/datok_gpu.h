@@ -117,19 +117,6 @@ typedef struct {
 } dtk_model_info;
 int dtk_model_get_info(const dtk_model *m, dtk_model_info *out);
 
-/* The walk's cache of hot table cells (speed only, never results): the cells the text in hand asks for most are kept
- * in LDS by the first-pass walk; the model learns them from a sampled log of the lookups the cache could not answer
- * (DESIGN.md section 4).  last_miss_rate: share of the lookups that went to the table in the last logged run
- * (-1: none yet). */
-typedef struct {
-  uint32_t enabled;      /* 0: this model's walk does not use the cache (general loop, pairs, wide cells) */
-  uint32_t generations;  /* tables built so far (the first one is empty) */
-  uint32_t cached_cells, capacity, known_cells;
-  uint32_t settled;      /* the last logged run missed too little for another table */
-  float last_miss_rate;
-} dtk_hot_stats;
-int dtk_model_hot_stats(const dtk_model *m, dtk_hot_stats *out);
-
 /* ---- batch: one data-parallel TransduceTokenWriter over n_docs documents.
  *      Each document is one reference call with a fresh writer
  *      (matrix.go:348 / datok.go:781).  A dtk_batch owns its device buffers
