@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--parity-docs", type=int, default=256, help="documents checked against the oracle before timing")
+    ap.add_argument("--e2e-only", action="store_true", help="(internal) the PCIe-inclusive block in a process of its own")
     return ap.parse_args()
 
 
@@ -116,8 +117,86 @@ def stage_times(batches, tok, steps):
     return {k: v / n for k, v in acc.items()}
 
 
+def e2e_only(args):
+    """The PCIe-inclusive block (see main): no torch in this process."""
+    from datok_amd import corpus
+    import datok_amd
+    n_docs = args.docs or 4096
+    n_streams = args.streams or 3
+    inputs = [corpus.german_docs(n_docs, args.doc_bytes, seed=2 + k) for k in range(n_streams)]
+    total = int(inputs[0][1][-1])
+    datok_amd.lib().dtk_set_device(0)
+    tok = datok_amd.load_tokenizer_file(args.model)
+    with datok_amd.Batch(total, n_docs) as b0:
+        b0.set_input(*inputs[0])
+        b0.run(tok, RUN_FLAGS)
+        tot = b0.totals()
+    reps = max(1, (24 if total <= (64 << 20) else 3) // len(inputs))
+    n_slices = reps * len(inputs)
+    pin = datok_amd.PinnedBuffer(total * n_slices)
+    for i in range(n_slices):
+        pin.array[i * total:(i + 1) * total] = inputs[i % len(inputs)][0]
+    big_off = np.concatenate([inputs[i % len(inputs)][1][(1 if i else 0):] + np.uint64(i * total) for i in range(n_slices)])
+    # plain upload rate of one batch's text, for reference
+    hb = datok_amd.Batch(total, n_docs)
+    t0 = time.perf_counter()
+    for i in range(6):
+        hb.set_input(pin.array[(i % n_slices) * total:(i % n_slices + 1) * total], inputs[0][1])
+        hb.sync()
+    h2d_ms = (time.perf_counter() - t0) / 6 * 1e3
+    hb.close()
+    B = datok_amd.Batch
+
+    def run_pipe(fields, depth):
+        """The corpus through dtk_pipeline_run, best of three; fields != 0: every slice's selected result arrays are
+        brought to page-locked host memory (dtk_pipeline_set_result_fields) and read there by the callback."""
+        pipe = datok_amd.Pipeline(total, n_docs, depth=depth)
+        pipe.set_chunking(datok_amd.Batch.AUTO_CHUNK if args.chunk < 0 else args.chunk, args.warm)
+        if fields:
+            pipe.set_result_fields(fields)
+        done = [0, 0]
+
+        def on_slice(first, n, bb):
+            done[0] += bb.totals()["n_tokens"]
+            if fields:
+                res = bb.result(copy=False)   # host pointers into the slice's page-locked buffers
+                if fields & B.R_TOK_RUNE:
+                    done[1] += int(res.tok_rend[-1]) + int(res.tok_off[-1])
+                if fields & B.R_EVENTS:
+                    done[1] += int(res.ev_bits[0, 0]) + int(res.doc_tail[-1])
+        pipe.run(tok, pin.array, big_off, RUN_FLAGS, on_slice)      # allocations, lane plans, page-locked buffers
+        best = 0.0
+        for rep in range(3):
+            done[0] = 0
+            t0 = time.perf_counter()
+            pipe.run(tok, pin.array, big_off, RUN_FLAGS, on_slice)
+            best = max(best, total * n_slices / (time.perf_counter() - t0) / 1e6)
+        assert done[0] >= tot["n_tokens"] * reps
+        pipe.close()
+        return round(best, 1)
+    f_off = B.R_TOK_RUNE | B.R_SENT | B.R_CSR | B.R_STATUS
+    f_ev = B.R_EVENTS | B.R_CSR | B.R_STATUS
+    out_bytes_off = 4 * (2 * tot["n_tokens"] + tot["n_sent"]) + 28 * n_docs
+    h2d = {"h2d_ms": round(h2d_ms, 4), "h2d_GBps": round(total / h2d_ms / 1e6, 2),
+           "end_to_end_MBps": run_pipe(0, 3), "slices": n_slices,
+           "with_results_MBps": run_pipe(f_off, 4),
+           "with_results_what": "host text in -> host offsets out: tok_rstart, tok_rend, sent, row offsets and status of "
+                                "every slice copied to page-locked host memory (%.2f B per input byte) under the next "
+                                "slices' upload and walk, read there by the callback; depth 4" % (out_bytes_off / total),
+           "with_event_bitmaps_MBps": run_pipe(f_ev, 4),
+           "with_event_bitmaps_what": "the same with the five event bitmaps + tail words instead of the offset arrays "
+                                      "(0.63 B per input byte: what a TokenWriter closure replay reads)",
+           "what": "a corpus of %d slices of one batch each in page-locked host memory -> dtk_pipeline_run (upload, walk, "
+                   "completion and download of different slices overlap); end_to_end_MBps: results stay in HBM; measured in a "
+                   "child process of bench.py without torch" % n_slices}
+    pin.close()
+    print(json.dumps(h2d))
+
+
 def main():
     args = parse()
+    if args.e2e_only:
+        return e2e_only(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -227,45 +306,22 @@ def main():
         elapsed = float(te.item())
     repair_rounds = max(int(bb.totals()["repair_rounds"]) for bb in batches)
 
-    # ---- PCIe inclusive: the same inputs as one corpus in page-locked host memory, through dtk_pipeline (slices of one
-    #      batch each, three in flight: the upload of a slice overlaps the walk of the others; completion per slice)
+    # ---- PCIe inclusive: the same inputs as one corpus in page-locked host memory, through dtk_pipeline.  In a process
+    #      of its own, without torch: a Go caller has none, and with torch initialised in the process the same pipeline's
+    #      downloads ran at two thirds of the rate (scripts/e2e_diag2.py WITH_TORCH=1: 24 against 36.7 GB/s).
     h2d = None
-    if rank == 0:
-        reps = max(1, (24 if total <= (64 << 20) else 3) // len(inputs))
-        n_slices = reps * len(inputs)
-        pin = datok_amd.PinnedBuffer(total * n_slices)
-        for i in range(n_slices):
-            pin.array[i * total:(i + 1) * total] = inputs[i % len(inputs)][0]
-        big_off = np.concatenate([inputs[i % len(inputs)][1][(1 if i else 0):] + np.uint64(i * total) for i in range(n_slices)])
-        # plain upload rate of one batch's text, for reference
-        hb = datok_amd.Batch(total, n_docs)
-        t0 = time.perf_counter()
-        for i in range(6):
-            hb.set_input(pin.array[(i % n_slices) * total:(i % n_slices + 1) * total], inputs[0][1])
-            hb.sync()
-        h2d_ms = (time.perf_counter() - t0) / 6 * 1e3
-        hb.close()
-        pipe = datok_amd.Pipeline(total, n_docs, depth=3)
-        pipe.set_chunking(datok_amd.Batch.AUTO_CHUNK if args.chunk < 0 else args.chunk, args.warm)
-        done = [0]
-
-        def on_slice(first, n, bb):
-            done[0] += bb.totals()["n_tokens"]
-        pipe.run(tok, pin.array, big_off, RUN_FLAGS, on_slice)      # allocations, lane plans
-        best = 0.0
-        for rep in range(3):
-            done[0] = 0
-            t0 = time.perf_counter()
-            pipe.run(tok, pin.array, big_off, RUN_FLAGS, on_slice)
-            e2e = time.perf_counter() - t0
-            best = max(best, total * n_slices / e2e / 1e6)
-        assert done[0] >= tot["n_tokens"] * reps
-        h2d = {"h2d_ms": round(h2d_ms, 4), "h2d_GBps": round(total / h2d_ms / 1e6, 2),
-               "end_to_end_MBps": round(best, 1), "slices": n_slices,
-               "what": "a corpus of %d slices of one batch each in page-locked host memory -> dtk_pipeline_run (depth 3: "
-                       "upload, walk and completion of different slices overlap); results stay in HBM" % n_slices}
-        pipe.close()
-        pin.close()
+    if rank == 0 and world == 1:
+        for bb in batches:   # (their HIP streams: the runtime has four hardware queues)
+            bb.close()
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--e2e-only", "--docs", str(n_docs), "--doc-bytes", str(args.doc_bytes),
+               "--model", args.model, "--chunk", str(args.chunk), "--warm", str(args.warm), "--streams", str(n_streams)]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        for line in r.stdout.splitlines():
+            if line.startswith("{"):
+                h2d = json.loads(line)
+        if h2d is None:
+            print("bench.py: end-to-end block failed: %s" % r.stderr[-400:], file=sys.stderr)
 
     # ---- offset gather to rank 0 over RCCL (config 5's exchange), outside the clock
     gather_ms, gather_hung, gather_err = None, False, None

@@ -27,6 +27,8 @@ EXPORTS = [
     "dtk_batch_status_host", "dtk_transduce_release", "dtk_transduce_result",
     "dtk_pipeline_create", "dtk_pipeline_free", "dtk_pipeline_set_chunking", "dtk_pipeline_run",
     "dtk_pinned_alloc", "dtk_pinned_free",
+    "dtk_batch_set_result_fields", "dtk_batch_download_begin", "dtk_pipeline_set_result_fields",
+    "dtk_batch_set_download_stream", "dtk_batch_download_stream", "dtk_batch_done", "dtk_batch_set_streams",
 ]
 
 
@@ -128,6 +130,14 @@ def lib():
     L.dtk_batch_stage_ms.argtypes = [vp, C.POINTER(C.c_float * 9)]
     L.dtk_batch_result_device.argtypes = [vp, C.POINTER(ResultView)]
     L.dtk_batch_result_host.argtypes = [vp, C.POINTER(ResultView)]
+    L.dtk_batch_set_result_fields.argtypes = [vp, u32]
+    L.dtk_batch_download_begin.argtypes = [vp]
+    L.dtk_batch_done.argtypes = [vp]
+    L.dtk_batch_set_streams.argtypes = [vp, vp, vp]
+    L.dtk_batch_set_download_stream.argtypes = [vp, vp]
+    L.dtk_batch_download_stream.argtypes = [vp]
+    L.dtk_batch_download_stream.restype = vp
+    L.dtk_pipeline_set_result_fields.argtypes = [vp, u32]
     L.dtk_transduce.argtypes = [vp, C.c_char_p, sz, u32, C.POINTER(vp), C.POINTER(sz), C.POINTER(u32)]
     L.dtk_transduce_replay.argtypes = L.dtk_transduce.argtypes
     L.dtk_transduce_release.restype = None

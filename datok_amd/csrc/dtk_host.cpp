@@ -975,6 +975,7 @@ struct dtk_batch {
   uint32_t repair_rounds = 0;        // of the last run
   const dtk_model *last_model = nullptr;
   uint32_t last_flags = 0;
+  uint64_t *d_csr = nullptr;  // tok_off | sent_off | text_off
   uint64_t *d_tok_off = nullptr, *d_sent_off = nullptr, *d_text_off = nullptr;
   uint64_t *d_tok_cnt = nullptr, *d_sent_cnt = nullptr, *d_text_cnt = nullptr;  // per-document counts
   uint64_t *d_scan_ws = nullptr;  // tile sums of the multi-block scan (many documents)
@@ -1021,12 +1022,41 @@ struct dtk_batch {
   uint32_t exp_runs = 0;  // DTK_EXP_SKIP experiments only
   DtkCompactArgs last_args{};
   dtk_totals totals{};
-  // host mirrors for dtk_batch_result_host
-  std::vector<uint64_t> h_tok_off, h_sent_off, h_text_off;
-  std::vector<int32_t> h_rstart, h_rend, h_sent;
-  std::vector<uint32_t> h_bstart, h_bend, h_ttok, h_tsent, h_status;
-  std::vector<uint32_t> h_bits, h_doc_tail;
+  // Results on the host (dtk_batch_result_host): page-locked buffers owned by the batch, filled by one chain of
+  // asynchronous copies on a stream of their own (dl_stream) -- the batch's own stream is free for the next kernels,
+  // the copy engine for the next slice's upload (PCIe is full duplex).  `fields` (DTK_R_*) selects what is copied.
+  enum { PB_TOK_OFF, PB_SENT_OFF, PB_TEXT_OFF, PB_RSTART, PB_REND, PB_BSTART, PB_BEND, PB_SENT, PB_TTOK, PB_TSENT,
+         PB_STATUS, PB_BITS, PB_TAIL, PB_N };
+  struct PinBuf { void *p = nullptr; size_t cap = 0; } pin[PB_N];
+  uint32_t fields = DTK_R_ALL;
+  hipStream_t dl_stream = nullptr;  // created with the first download, unless the caller lends one (a pipeline's slices share one:
+  bool dl_own = false;              //  the runtime maps streams onto four hardware queues, and streams that share a queue serialise)
+  hipEvent_t ev_ran = nullptr;      // behind the last launch of dtk_batch_run (dtk_batch_done)
+  // Lent streams (dtk_batch_set_streams): the batches of a pipeline share one stream for their kernels and one for their
+  // uploads -- the runtime has four hardware queues, and a pipeline of any depth then needs three (kernels, uploads,
+  // downloads).  The upload's end is an event the kernels wait for.
+  bool stream_own = true;
+  hipStream_t up_stream = nullptr;  // null: uploads run on `stream`
+  hipEvent_t ev_up = nullptr;
+  bool up_pending = false;          // an upload on up_stream has not been waited for yet
+  uint32_t eager_fields = 0;  // the last run's k_to_host was asked for these (0: none); finish() decides whether it counts
+  bool results_changed = false;  // finish() had to touch the result arrays after the run (repair, growth, EOT kernel, exact pass)
+  hipEvent_t ev_dl = nullptr;  // behind the batch's copies on the (possibly shared) download stream
+  bool dl_waited = true;
+  bool dl_begun = false;    // the copies of the last run's results have been enqueued
+  uint32_t dl_fields = 0;   // ... these fields
 };
+
+// page-locked memory for n bytes in `pb` (grown with a quarter of slack: allocation costs milliseconds)
+static int pin_fit(dtk_batch::PinBuf &pb, size_t n) {
+  if (n <= pb.cap && pb.p) return DTK_OK;
+  if (pb.p) HIP_TRY(hipHostFree(pb.p));
+  pb.p = nullptr; pb.cap = 0;
+  const size_t cap = std::max<size_t>(n + n / 4, 256);
+  HIP_TRY(hipHostMalloc(&pb.p, cap, hipHostMallocDefault));
+  pb.cap = cap;
+  return DTK_OK;
+}
 
 static int alloc_outputs(dtk_batch *b, uint64_t tok, uint64_t sent, uint64_t text) {
   auto grow = [&](auto *&p, uint64_t n) -> int {
@@ -1088,9 +1118,10 @@ extern "C" int dtk_batch_create(uint64_t max_bytes, uint32_t max_docs, dtk_batch
 
   B_TRY(hipMalloc((void **)&b->d_chunk_off, ((uint64_t)max_docs + 1) * 4));
   B_TRY(hipMalloc((void **)&b->d_big_docs, ((uint64_t)max_docs + 1) * 4));
-  B_TRY(hipMalloc((void **)&b->d_tok_off, ((uint64_t)max_docs + 1) * 8));
-  B_TRY(hipMalloc((void **)&b->d_sent_off, ((uint64_t)max_docs + 1) * 8));
-  B_TRY(hipMalloc((void **)&b->d_text_off, ((uint64_t)max_docs + 1) * 8));
+  // the three row-offset arrays, carved from one block per run (n_docs + 1 words each, back to back: one copy brings
+  // them to the host)
+  B_TRY(hipMalloc((void **)&b->d_csr, 3 * ((uint64_t)max_docs + 1) * 8));
+  b->d_tok_off = b->d_csr; b->d_sent_off = b->d_csr + ((uint64_t)max_docs + 1); b->d_text_off = b->d_csr + 2 * ((uint64_t)max_docs + 1);
   B_TRY(hipMalloc((void **)&b->d_doc_ns, ((uint64_t)max_docs + 1) * 4));
   B_TRY(hipMalloc((void **)&b->d_scan_ws, ((uint64_t)max_docs / 2048 + 2) * 4 * 8));
   B_TRY(hipMalloc((void **)&b->d_out_off, ((uint64_t)max_docs + 1) * 8));
@@ -1110,11 +1141,18 @@ extern "C" int dtk_batch_create(uint64_t max_bytes, uint32_t max_docs, dtk_batch
 extern "C" void dtk_batch_free(dtk_batch *b) {
   if (!b) return;
   if (b->stream) (void)hipStreamSynchronize(b->stream);
+  if (b->up_stream) (void)hipStreamSynchronize(b->up_stream);
+  if (b->ev_up) (void)hipEventDestroy(b->ev_up);
+  if (b->dl_begun && !b->dl_waited) (void)hipEventSynchronize(b->ev_dl);
+  if (b->dl_stream && b->dl_own) (void)hipStreamDestroy(b->dl_stream);
+  if (b->ev_ran) (void)hipEventDestroy(b->ev_ran);
+  if (b->ev_dl) (void)hipEventDestroy(b->ev_dl);
+  for (auto &pb : b->pin)
+    if (pb.p) (void)hipHostFree(pb.p);
   void *ptrs[] = {b->d_text_own, b->d_off_own, b->d_sym, b->d_rsbits, b->d_bits, b->d_acc, b->d_redo, b->d_chunk_off, b->d_blk_doc, b->d_big_docs,
                   b->d_lane_doc, b->d_lane_cnt, b->d_lane_start, b->d_lane_end, b->d_lane_plan,
                   b->d_seg_tab, b->d_seg_sum, b->d_seg_in,
-                  b->d_tok_off,
-                  b->d_sent_off, b->d_text_off, b->d_rstart, b->d_rend, b->d_sent,
+                  b->d_csr, b->d_rstart, b->d_rend, b->d_sent,
                   b->d_bstart, b->d_bend, b->d_ttok, b->d_tsent,
                   b->d_sbefore, b->d_ts_end, b->d_doc_ns, b->d_scan_ws, b->d_rws, b->d_out_off, b->d_out,
                   b->d_exact_ids, b->d_exact_cnt, b->d_exact_off, b->d_calls};
@@ -1124,11 +1162,34 @@ extern "C" void dtk_batch_free(dtk_batch *b) {
   if (b->h_off_pin) (void)hipHostFree(b->h_off_pin);
   for (hipEvent_t e : b->ev)
     if (e) (void)hipEventDestroy(e);
-  if (b->stream) (void)hipStreamDestroy(b->stream);
+  if (b->stream && b->stream_own) (void)hipStreamDestroy(b->stream);
   delete b;
 }
 
 extern "C" void *dtk_batch_stream(dtk_batch *b) { return b ? (void *)b->stream : nullptr; }
+
+// Everything this batch has enqueued so far has finished.  With a stream of its own: the stream; on a lent stream
+// (shared with other batches) only the batch's own last run, by its event.
+static int wait_own(dtk_batch *b) {
+  if (b->up_pending) { HIP_TRY(hipEventSynchronize(b->ev_up)); }
+  if (b->stream_own || !b->ran || !b->ev_ran) HIP_TRY(hipStreamSynchronize(b->stream));
+  else HIP_TRY(hipEventSynchronize(b->ev_ran));
+  return DTK_OK;
+}
+
+extern "C" int dtk_batch_set_streams(dtk_batch *b, void *compute, void *upload) {
+  if (!b) return DTK_E_ARG;
+  int rc = wait_own(b);
+  if (rc != DTK_OK) return rc;
+  if (compute) {
+    if (b->stream_own && b->stream) HIP_TRY(hipStreamDestroy(b->stream));
+    b->stream = (hipStream_t)compute;
+    b->stream_own = false;
+  }
+  b->up_stream = (hipStream_t)upload;
+  if (upload && !b->ev_up) HIP_TRY(hipEventCreateWithFlags(&b->ev_up, hipEventDisableTiming));
+  return DTK_OK;
+}
 
 extern "C" int dtk_batch_set_input(dtk_batch *b, const uint8_t *text, const uint64_t *doc_off, uint32_t n_docs) {
   if (!b || !doc_off || n_docs == 0) return DTK_E_ARG;
@@ -1141,10 +1202,12 @@ extern "C" int dtk_batch_set_input(dtk_batch *b, const uint8_t *text, const uint
   const uint64_t total = doc_off[n_docs];
   if (total > b->max_bytes || total + n_docs + 64 >= (1ull << 32)) return DTK_E_CAPACITY;  // 32-bit position bits
   if (total && !text) return DTK_E_ARG;
-  HIP_TRY(hipStreamSynchronize(b->stream));  // previous run may still read the buffers
-  if (total) HIP_TRY(hipMemcpyAsync(b->d_text_own, text, total, hipMemcpyHostToDevice, b->stream));
+  { int rc = wait_own(b); if (rc != DTK_OK) return rc; }  // the previous run may still read the buffers
+  hipStream_t us = b->up_stream ? b->up_stream : b->stream;
+  if (total) HIP_TRY(hipMemcpyAsync(b->d_text_own, text, total, hipMemcpyHostToDevice, us));
   memcpy(b->h_off_pin, doc_off, ((size_t)n_docs + 1) * 8);
-  HIP_TRY(hipMemcpyAsync(b->d_off_own, b->h_off_pin, ((uint64_t)n_docs + 1) * 8, hipMemcpyHostToDevice, b->stream));
+  HIP_TRY(hipMemcpyAsync(b->d_off_own, b->h_off_pin, ((uint64_t)n_docs + 1) * 8, hipMemcpyHostToDevice, us));
+  if (b->up_stream) { HIP_TRY(hipEventRecord(b->ev_up, us)); b->up_pending = true; }
   // the lane plan only depends on the offsets: a stream of equally shaped batches keeps it
   const bool same = b->plan_valid && b->d_off == b->d_off_own && b->n_docs == n_docs &&
                     b->h_doc_off.size() == (size_t)n_docs + 1 &&
@@ -1210,7 +1273,7 @@ static int plan_lanes(dtk_batch *b) {
       blk[i] = d;
     }
     blk[nblk + 1] = b->n_docs - 1;
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    { const int rc_ = wait_own(b); if (rc_ != DTK_OK) return rc_; }
     HIP_TRY(hipMemcpy(b->d_blk_doc, blk.data(), blk.size() * 4, hipMemcpyHostToDevice));
   }
   {
@@ -1303,7 +1366,7 @@ static int plan_lanes(dtk_batch *b) {
     b->seg_cap = (uint32_t)cap;
   }
   b->n_segs = ns;
-  HIP_TRY(hipStreamSynchronize(b->stream));
+  { const int rc_ = wait_own(b); if (rc_ != DTK_OK) return rc_; }
   HIP_TRY(hipMemcpy(b->d_seg_tab, seg_doc.data(), (size_t)ns * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(b->d_seg_tab + b->seg_cap, seg_lane0.data(), (size_t)ns * 4, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(b->d_seg_tab + 2 * (size_t)b->seg_cap, seg_nl.data(), (size_t)ns * 4, hipMemcpyHostToDevice));
@@ -1401,12 +1464,20 @@ static int repair_round(dtk_batch *b, const dtk_model *m, const DtkWalkArgs *w, 
   return DTK_OK;
 }
 
+static int launch_to_host(dtk_batch *b);
+
 extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
   if (!m || !b) return DTK_E_ARG;
   if (b->n_docs == 0 || !b->d_off) return DTK_E_STATE;
   if (m->device != b->device) return DTK_E_ARG;
   int prc = plan_lanes(b);
   if (prc != DTK_OK) return prc;
+  if (b->dl_begun && !b->dl_waited) { HIP_TRY(hipEventSynchronize(b->ev_dl)); b->dl_waited = true; }  // (the last run's results on their way out)
+  b->dl_begun = false;
+  if (b->up_pending) {  // the kernels wait for the input's upload on the other stream
+    HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_up, 0));
+    b->up_pending = false;
+  }
   b->last_model = m;
   b->last_flags = flags;
   b->repair_rounds = 0;
@@ -1429,6 +1500,7 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
     // check words -- cleared together with the two event arrays by one launch
     const size_t nd = b->n_docs;
     uint8_t *q = b->d_acc;
+    b->d_tok_off = b->d_csr; b->d_sent_off = b->d_csr + (nd + 1); b->d_text_off = b->d_csr + 2 * (nd + 1);
     b->d_totals = (uint64_t *)q; q += DTK_TOTALS_BYTES;  // (the striped lookup counters right behind the totals)
     b->d_tok_cnt = (uint64_t *)q; q += (nd + 1) * 8;
     b->d_sent_cnt = (uint64_t *)q; q += (nd + 1) * 8;
@@ -1517,11 +1589,29 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
   if (rc != DTK_OK) return rc;
   STAGE(9);
 #undef STAGE
+  b->eager_fields = 0;
+  b->results_changed = false;
+  if ((b->fields & DTK_R_EAGER) && !(skip & 8)) {
+    rc = launch_to_host(b);
+    if (rc != DTK_OK) return rc;
+  }
   HIP_TRY(hipMemcpyAsync(b->h_totals, b->d_totals, DTK_TOTALS_BYTES, hipMemcpyDeviceToHost, s));
+  if (!b->ev_ran) HIP_TRY(hipEventCreateWithFlags(&b->ev_ran, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(b->ev_ran, s));
   b->ran = true;
   b->totals_valid = false;
   b->render_flags = 0xFFFFFFFFu;
   return DTK_OK;
+}
+
+// 1: everything dtk_batch_run enqueued has finished (dtk_batch_totals & co. will not wait for the GPU unless the
+// run needs a repair); 0: not yet; never blocks.  (An event query: hipStreamQuery on a busy stream was seen to
+// return only when the stream had drained.)
+extern "C" int dtk_batch_done(dtk_batch *b) {
+  if (!b || !b->ran || !b->ev_ran) return 0;
+  const hipError_t e = hipEventQuery(b->ev_ran);
+  if (e != hipSuccess) (void)hipGetLastError();
+  return e == hipSuccess ? 1 : 0;
 }
 
 extern "C" int dtk_batch_set_profiling(dtk_batch *b, int enable) {
@@ -1542,8 +1632,7 @@ extern "C" int dtk_batch_stage_ms(dtk_batch *b, float ms[DTK_N_STAGES]) {
 
 extern "C" int dtk_batch_sync(dtk_batch *b) {
   if (!b) return DTK_E_ARG;
-  HIP_TRY(hipStreamSynchronize(b->stream));
-  return DTK_OK;
+  return wait_own(b);
 }
 
 // The exact pass (k_exact_doc): documents flagged ST_IRREGULAR by the walk are walked again by one lane each,
@@ -1615,7 +1704,7 @@ static int run_exact(dtk_batch *b) {
 static int finish(dtk_batch *b) {
   if (!b->ran) return DTK_E_STATE;
   if (b->totals_valid) return DTK_OK;
-  HIP_TRY(hipStreamSynchronize(b->stream));
+  { const int rc_ = wait_own(b); if (rc_ != DTK_OK) return rc_; }  // (on a lent stream: this batch's run, not its neighbours')
   // Speculation check failed somewhere: those documents are repaired from the last owning lane before their first
   // bad lane on (fix records, clear, re-link, re-walk, re-verify) until every lane chains.  Rounds enqueued ahead of
   // time (dtk_batch_run) have run on the device already; what is still broken behind them is repaired from here,
@@ -1626,6 +1715,7 @@ static int finish(dtk_batch *b) {
       if (hnb[r] != 0) b->repair_rounds++;
     uint32_t left = hnb[b->dev_rounds];
     if (left != 0) {
+      b->results_changed = true;
       const dtk_model *m = b->last_model;
       hipStream_t s = b->stream;
       DtkWalkArgs w = walk_args(b);
@@ -1684,6 +1774,7 @@ static int finish(dtk_batch *b) {
   const uint64_t nt = b->h_totals[0], ns = b->h_totals[1], nx = b->h_totals[2];
   b->n_invalid = b->h_totals[6] == b->epoch ? 1u : 0u;  // (the number of the last run that saw one: k_symbolize)
   if (nt > b->tok_cap || ns > b->sent_cap || nx > b->text_cap) {
+    b->results_changed = true;
     int rc = alloc_outputs(b, nt + nt / 8 + 16, ns + ns / 8 + 16, nx + nx / 8 + 16);
     if (rc != DTK_OK) return rc;
     rc = launch_compact2(b, 3);
@@ -1695,6 +1786,7 @@ static int finish(dtk_batch *b) {
   {
     const bool eot = (b->h_totals[7] >> 32) != 0;
     if (eot && !b->ran_full) {
+      b->results_changed = true;
       int rc = launch_compact2(b, 2);
       if (rc != DTK_OK) return rc;
       HIP_TRY(hipMemcpyAsync(b->h_totals + 7, b->d_totals + 7, 8, hipMemcpyDeviceToHost, b->stream));
@@ -1705,8 +1797,15 @@ static int finish(dtk_batch *b) {
   // documents whose calls are not in position order (ST_IRREGULAR): their rows come from the exact pass
   b->h_exact_ids.clear(); b->h_exact_off.assign(1, 0); b->h_calls.clear();
   if ((uint32_t)b->h_totals[7] != 0) {
+    b->results_changed = true;
     int rc = run_exact(b);
     if (rc != DTK_OK) return rc;
+  }
+  // the arrays k_to_host brought over inside the run count if the kernel made its copy and nothing was touched since
+  if (b->eager_fields && !b->results_changed && b->h_totals[11] == b->epoch) {
+    b->dl_begun = true;
+    b->dl_waited = true;
+    b->dl_fields = b->eager_fields;
   }
   b->totals.n_docs = b->n_docs;
   b->totals.n_bytes = b->total;
@@ -1753,34 +1852,151 @@ extern "C" int dtk_batch_result_device(dtk_batch *b, dtk_result_view *o) {
   return DTK_OK;
 }
 
-extern "C" int dtk_batch_result_host(dtk_batch *b, dtk_result_view *o) {
-  if (!b || !o) return DTK_E_ARG;
-  int rc = finish(b);
-  if (rc != DTK_OK) return rc;
-  const uint64_t nd = b->n_docs, nt = b->totals.n_tokens, ns = b->totals.n_sent, nx = b->totals.n_texts;
-  auto get = [&](auto &vec, const void *src, uint64_t n) -> int {
-    vec.resize(std::max<uint64_t>(n, 1));
-    if (n) HIP_TRY(hipMemcpy(vec.data(), src, n * sizeof(vec[0]), hipMemcpyDeviceToHost));
+extern "C" int dtk_batch_set_result_fields(dtk_batch *b, uint32_t fields) {
+  if (!b || (fields & ~(uint32_t)(DTK_R_ALL | DTK_R_EAGER))) return DTK_E_ARG;
+  b->fields = fields;
+  return DTK_OK;
+}
+
+// DTK_R_EAGER: the selected arrays leave for the host inside the run, by a kernel behind the compaction that reads
+// the sizes where they are -- on the device (k_to_host).  Page-locked buffers sized like the device arrays.
+static int launch_to_host(dtk_batch *b) {
+  const uint32_t f = b->fields;
+  DtkToHostArgs a{};
+  const uint64_t nd = b->n_docs;
+  auto add = [&](int which, const void *src, uint64_t bytes_or_elem, int count_from, uint64_t cap) -> int {
+    const uint64_t need = count_from >= 0 ? cap * bytes_or_elem : bytes_or_elem;
+    int rc = pin_fit(b->pin[which], (size_t)need);
+    if (rc != DTK_OK) return rc;
+    void *dp = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&dp, b->pin[which].p, 0));
+    a.src[a.n] = src; a.dst[a.n] = dp; a.bytes[a.n] = bytes_or_elem; a.count_from[a.n] = count_from;
+    a.cap[a.n] = count_from >= 0 ? b->pin[which].cap / bytes_or_elem : 0;
+    a.n++;
     return DTK_OK;
   };
-  if ((rc = get(b->h_tok_off, b->d_tok_off, nd + 1))) return rc;
-  if ((rc = get(b->h_sent_off, b->d_sent_off, nd + 1))) return rc;
-  if ((rc = get(b->h_text_off, b->d_text_off, nd + 1))) return rc;
-  if ((rc = get(b->h_rstart, b->d_rstart, nt))) return rc;
-  if ((rc = get(b->h_rend, b->d_rend, nt))) return rc;
-  if ((rc = get(b->h_bstart, b->d_bstart, nt))) return rc;
-  if ((rc = get(b->h_bend, b->d_bend, nt))) return rc;
-  if ((rc = get(b->h_sent, b->d_sent, ns))) return rc;
-  if ((rc = get(b->h_ttok, b->d_ttok, nx))) return rc;
-  if ((rc = get(b->h_tsent, b->d_tsent, nx))) return rc;
-  if ((rc = get(b->h_status, b->d_status, nd))) return rc;
-  if ((rc = get(b->h_bits, b->d_bits, (uint64_t)EVB_KINDS * b->bit_words))) return rc;
-  if ((rc = get(b->h_doc_tail, b->d_doc_tail, nd))) return rc;
-  o->tok_off = b->h_tok_off.data(); o->sent_off = b->h_sent_off.data(); o->text_off = b->h_text_off.data();
-  o->tok_rstart = b->h_rstart.data(); o->tok_rend = b->h_rend.data();
-  o->tok_bstart = b->h_bstart.data(); o->tok_bend = b->h_bend.data();
-  o->sent = b->h_sent.data(); o->text_tok_end = b->h_ttok.data(); o->text_sent_end = b->h_tsent.data();
-  o->status = b->h_status.data(); o->ev_bits = b->h_bits.data(); o->ev_words = b->bit_words; o->doc_tail = b->h_doc_tail.data();
+  int rc;
+  if (f & DTK_R_TOK_RUNE) {
+    if ((rc = add(dtk_batch::PB_RSTART, b->d_rstart, 4, 0, b->tok_cap))) return rc;
+    if ((rc = add(dtk_batch::PB_REND, b->d_rend, 4, 0, b->tok_cap))) return rc;
+  }
+  if (f & DTK_R_TOK_BYTE) {
+    if ((rc = add(dtk_batch::PB_BSTART, b->d_bstart, 4, 0, b->tok_cap))) return rc;
+    if ((rc = add(dtk_batch::PB_BEND, b->d_bend, 4, 0, b->tok_cap))) return rc;
+  }
+  if (f & DTK_R_EVENTS) {
+    if ((rc = add(dtk_batch::PB_BITS, b->d_bits, (uint64_t)EVB_KINDS * b->bit_words * 4, -1, 0))) return rc;
+    if ((rc = add(dtk_batch::PB_TAIL, b->d_doc_tail, nd * 4, -1, 0))) return rc;
+  }
+  if (f & DTK_R_SENT)
+    if ((rc = add(dtk_batch::PB_SENT, b->d_sent, 4, 1, b->sent_cap))) return rc;
+  if (f & DTK_R_TEXTS) {
+    if ((rc = add(dtk_batch::PB_TTOK, b->d_ttok, 4, 2, b->text_cap))) return rc;
+    if ((rc = add(dtk_batch::PB_TSENT, b->d_tsent, 4, 2, b->text_cap))) return rc;
+  }
+  if (f & DTK_R_CSR)
+    if ((rc = add(dtk_batch::PB_TOK_OFF, b->d_csr, 3 * (nd + 1) * 8, -1, 0))) return rc;
+  if (f & DTK_R_STATUS)
+    if ((rc = add(dtk_batch::PB_STATUS, b->d_status, nd * 4, -1, 0))) return rc;
+  if (a.n == 0) return DTK_OK;
+  a.totals = b->d_totals;
+  a.skip_if = b->last_args.skip_if;
+  a.done = b->d_totals + 11;
+  a.epoch = b->epoch;
+  if (dtk_launch_to_host(&a, b->stream)) return hip_fail(hipGetLastError(), "results to the host");
+  b->eager_fields = f & DTK_R_ALL;
+  return DTK_OK;
+}
+
+// Completes the run (as dtk_batch_totals: speculation check, repairs, capacity check -- the batch's stream is idle
+// afterwards) and enqueues the copies of the selected result arrays on the download stream.  Returns at once.
+extern "C" int dtk_batch_set_download_stream(dtk_batch *b, void *stream) {
+  if (!b) return DTK_E_ARG;
+  if (b->dl_begun && !b->dl_waited) { HIP_TRY(hipEventSynchronize(b->ev_dl)); b->dl_waited = true; }
+  if (b->dl_stream && b->dl_own) HIP_TRY(hipStreamDestroy(b->dl_stream));
+  b->dl_stream = (hipStream_t)stream;
+  b->dl_own = false;
+  return DTK_OK;
+}
+
+extern "C" void *dtk_batch_download_stream(dtk_batch *b) {
+  if (!b) return nullptr;
+  if (!b->dl_stream) {
+    if (hipStreamCreateWithFlags(&b->dl_stream, hipStreamNonBlocking) != hipSuccess) { b->dl_stream = nullptr; return nullptr; }
+    b->dl_own = true;
+  }
+  return (void *)b->dl_stream;
+}
+
+extern "C" int dtk_batch_download_begin(dtk_batch *b) {
+  if (!b) return DTK_E_ARG;
+  int rc = finish(b);
+  if (rc != DTK_OK) return rc;
+
+  const uint32_t sel = b->fields & DTK_R_ALL;
+  if (b->dl_begun && (b->dl_fields & sel) == sel) return DTK_OK;
+  const uint32_t want = sel & ~(b->dl_begun ? b->dl_fields : 0u);
+  if (!dtk_batch_download_stream(b)) return hip_fail(hipGetLastError(), "download stream");
+  const uint64_t nd = b->n_docs, nt = b->totals.n_tokens, ns = b->totals.n_sent, nx = b->totals.n_texts;
+  auto get = [&](int which, const void *src, uint64_t bytes) -> int {
+    int rc2 = pin_fit(b->pin[which], (size_t)bytes);
+    if (rc2 != DTK_OK) return rc2;
+    if (bytes) HIP_TRY(hipMemcpyAsync(b->pin[which].p, src, (size_t)bytes, hipMemcpyDeviceToHost, b->dl_stream));
+    return DTK_OK;
+  };
+  // (the large arrays first: the small ones ride behind them)
+  if (want & DTK_R_TOK_RUNE) {
+    if ((rc = get(dtk_batch::PB_RSTART, b->d_rstart, nt * 4))) return rc;
+    if ((rc = get(dtk_batch::PB_REND, b->d_rend, nt * 4))) return rc;
+  }
+  if (want & DTK_R_TOK_BYTE) {
+    if ((rc = get(dtk_batch::PB_BSTART, b->d_bstart, nt * 4))) return rc;
+    if ((rc = get(dtk_batch::PB_BEND, b->d_bend, nt * 4))) return rc;
+  }
+  if (want & DTK_R_EVENTS) {
+    if ((rc = get(dtk_batch::PB_BITS, b->d_bits, (uint64_t)EVB_KINDS * b->bit_words * 4))) return rc;
+    if ((rc = get(dtk_batch::PB_TAIL, b->d_doc_tail, nd * 4))) return rc;
+  }
+  if (want & DTK_R_SENT)
+    if ((rc = get(dtk_batch::PB_SENT, b->d_sent, ns * 4))) return rc;
+  if (want & DTK_R_TEXTS) {
+    if ((rc = get(dtk_batch::PB_TTOK, b->d_ttok, nx * 4))) return rc;
+    if ((rc = get(dtk_batch::PB_TSENT, b->d_tsent, nx * 4))) return rc;
+  }
+  if (want & DTK_R_CSR)  // (tok_off | sent_off | text_off lie back to back: dtk_batch_run)
+    if ((rc = get(dtk_batch::PB_TOK_OFF, b->d_csr, 3 * (nd + 1) * 8))) return rc;
+  if (want & DTK_R_STATUS)
+    if ((rc = get(dtk_batch::PB_STATUS, b->d_status, nd * 4))) return rc;
+  if (!b->ev_dl) HIP_TRY(hipEventCreateWithFlags(&b->ev_dl, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(b->ev_dl, b->dl_stream));
+  b->dl_waited = false;
+  b->dl_fields = (b->dl_begun ? b->dl_fields : 0u) | want;
+  b->dl_begun = true;
+  return DTK_OK;
+}
+
+extern "C" int dtk_batch_result_host(dtk_batch *b, dtk_result_view *o) {
+  if (!b || !o) return DTK_E_ARG;
+  int rc = dtk_batch_download_begin(b);
+  if (rc != DTK_OK) return rc;
+  if (!b->dl_waited) { HIP_TRY(hipEventSynchronize(b->ev_dl)); b->dl_waited = true; }
+  const uint32_t f = b->dl_fields;
+  auto at = [&](int which, uint32_t field) -> const void * { return (f & field) ? b->pin[which].p : nullptr; };
+  memset(o, 0, sizeof(*o));
+  o->tok_off = (const uint64_t *)at(dtk_batch::PB_TOK_OFF, DTK_R_CSR);
+  o->sent_off = o->tok_off ? o->tok_off + (b->n_docs + 1) : nullptr;
+  o->text_off = o->tok_off ? o->tok_off + 2 * ((uint64_t)b->n_docs + 1) : nullptr;
+  o->tok_rstart = (const int32_t *)at(dtk_batch::PB_RSTART, DTK_R_TOK_RUNE);
+  o->tok_rend = (const int32_t *)at(dtk_batch::PB_REND, DTK_R_TOK_RUNE);
+  o->tok_bstart = (const uint32_t *)at(dtk_batch::PB_BSTART, DTK_R_TOK_BYTE);
+  o->tok_bend = (const uint32_t *)at(dtk_batch::PB_BEND, DTK_R_TOK_BYTE);
+  o->sent = (const int32_t *)at(dtk_batch::PB_SENT, DTK_R_SENT);
+  o->text_tok_end = (const uint32_t *)at(dtk_batch::PB_TTOK, DTK_R_TEXTS);
+  o->text_sent_end = (const uint32_t *)at(dtk_batch::PB_TSENT, DTK_R_TEXTS);
+  o->status = (const uint32_t *)at(dtk_batch::PB_STATUS, DTK_R_STATUS);
+  o->ev_bits = (const uint32_t *)at(dtk_batch::PB_BITS, DTK_R_EVENTS);
+  o->ev_words = b->bit_words;
+  o->doc_tail = (const uint32_t *)at(dtk_batch::PB_TAIL, DTK_R_EVENTS);
   o->n_exact = (uint32_t)b->h_exact_ids.size();
   o->exact_doc = b->h_exact_ids.data(); o->exact_off = b->h_exact_off.data(); o->calls = (const dtk_call *)b->h_calls.data();
   return DTK_OK;

@@ -300,9 +300,27 @@ struct DtkRenderArgs {
   uint64_t out_total;
 };
 
+// Results straight into page-locked host memory from the batch's own stream (k_to_host): the sizes of the offset
+// arrays are only known on the device when the copies have to be enqueued, so a copy engine cannot be asked ahead of
+// time -- a kernel can: it reads the totals and streams the rows over the link with 16-byte stores.
+#define DTK_TOHOST_MAX 14
+struct DtkToHostArgs {
+  const void *src[DTK_TOHOST_MAX];
+  void *dst[DTK_TOHOST_MAX];           // mapped page-locked host memory
+  uint64_t bytes[DTK_TOHOST_MAX];      // size in bytes (count_from < 0), else bytes per element
+  int32_t count_from[DTK_TOHOST_MAX];  // < 0: fixed size; 0..2: totals[count_from] elements
+  uint64_t cap[DTK_TOHOST_MAX];        // elements the destination holds (count_from >= 0)
+  uint32_t n;
+  const uint64_t *totals;              // device totals block (scan3)
+  const uint32_t *skip_if;             // documents still to repair: nothing is copied unless this is 0 (null: copy)
+  uint64_t *done;                      // device word: set to the run's epoch when the copy was made
+  uint64_t epoch;
+};
+
 #ifdef __cplusplus
 extern "C" {
 #endif
+int dtk_launch_to_host(const struct DtkToHostArgs *args, void *stream);
 // launchers (dtk_kernels.hip); stream is a hipStream_t
 int dtk_launch_symbolize(const uint8_t *text, const uint64_t *doc_off, uint32_t n_docs,
                          uint64_t total, const struct DtkSigmaDev *sig, void *sym, int padded,

@@ -2876,6 +2876,56 @@ __global__ __launch_bounds__(SCAN1_TB) void k_scan3(const uint64_t *ca, const ui
   }
 }
 
+// ------------------------------------------------------------------ results to the host
+//
+// One launch behind the compaction: every selected result array goes to its page-locked host buffer (DtkToHostArgs).
+// Sources and destinations are 16-byte aligned (hipMalloc / hipHostMalloc); a wave writes 1 KiB of consecutive bytes
+// per instruction -- posted writes over the link, nothing waits for them but the end of the wave.  The last block
+// to finish (one counter add per block) ... is not needed: the host only looks after the stream's event.
+// The kernel must not get in the way of the walks of other batches: with 2048 waves storing as fast as they could the
+// stores queued up in every CU's memory pipeline and a k_spec_both beside it took 0.49 instead of 0.13 ms.  So few
+// waves (one per block, spread over the CUs), each with ONE 1 KiB store instruction in flight: 128 KiB under way on
+// the link at any time is what ~50 GB/s x 2 us of round trip need.
+#ifndef DTK_TOHOST_WAVES
+#define DTK_TOHOST_WAVES 128u
+#endif
+__global__ __launch_bounds__(WAVE) void k_to_host(DtkToHostArgs A) {
+  if (A.skip_if && *A.skip_if != 0u) return;
+  // (every wave decides alike: a count beyond its buffer means the host has to grow buffers and copy by itself)
+  bool fits = true;
+  for (uint32_t i = 0; i < A.n; i++)
+    if (A.count_from[i] >= 0 && A.totals[A.count_from[i]] > A.cap[i]) fits = false;
+  if (!fits) return;
+  const uint32_t lane = threadIdx.x;
+  for (uint32_t i = 0; i < A.n; i++) {
+    const uint64_t bytes = A.count_from[i] >= 0 ? A.totals[A.count_from[i]] * A.bytes[i] : A.bytes[i];
+    const uint4 *__restrict__ s16 = reinterpret_cast<const uint4 *>(A.src[i]);
+    uint4 *__restrict__ d16 = reinterpret_cast<uint4 *>(A.dst[i]);
+    const uint64_t n16 = bytes >> 4;
+    // pieces of 64 x 16 B, dealt round-robin to the waves (rotated by the array's number: the short arrays do not
+    // all land on wave 0)
+    for (uint64_t p = (blockIdx.x + gridDim.x - i % gridDim.x) % gridDim.x; p * WAVE < n16; p += gridDim.x) {
+      const uint64_t j = p * WAVE + lane;
+      if (j < n16) {
+        const uint4 v = s16[j];
+        d16[j] = v;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // one store under way per wave
+    }
+    if (blockIdx.x == i % gridDim.x && lane < (bytes & 15u))
+      reinterpret_cast<uint8_t *>(A.dst[i])[(n16 << 4) + lane] = reinterpret_cast<const uint8_t *>(A.src[i])[(n16 << 4) + lane];
+  }
+  if (blockIdx.x == 0 && lane == 0) *A.done = A.epoch;
+}
+
+static uint32_t g_tohost_waves = DTK_TOHOST_WAVES;
+extern "C" void dtk_debug_set_tohost_waves(uint32_t n) { g_tohost_waves = n ? n : DTK_TOHOST_WAVES; }
+
+extern "C" int dtk_launch_to_host(const DtkToHostArgs *args, void *stream) {
+  hipLaunchKernelGGL(k_to_host, dim3(g_tohost_waves), dim3(WAVE), 0, (hipStream_t)stream, *args);
+  return (int)hipGetLastError();
+}
+
 // ---------------------------------------------------------------- launchers
 
 // ---- clears: the accumulator block and the two event arrays of a run in one launch (16-byte stores)

@@ -16,7 +16,13 @@ struct dtk_pipeline {
   uint32_t slice_docs = 0;
   std::vector<dtk_batch *> slots;
   std::vector<uint32_t> first, count;  // the slice each slot holds
+  std::vector<uint8_t> touched;        // an upload into the slot may be under way (error paths wait for it)
   std::vector<uint64_t> off;           // rebased offsets of the slice being submitted
+  uint32_t fields = 0;                 // DTK_R_*: result arrays brought to the host for every slice (0: none)
+  // Three streams for the whole pipeline, whatever its depth: uploads, kernels, downloads (the HIP runtime maps streams
+  // onto four hardware queues; streams that share a queue serialise -- a stream per slot made depth 4 slower than 3).
+  // Slices take turns on each: the link carries slice i + 2 in and slice i out while slice i + 1 is walked.
+  hipStream_t s_up = nullptr, s_run = nullptr, s_down = nullptr;
 };
 
 extern "C" void *dtk_pinned_alloc(size_t n) {
@@ -35,14 +41,25 @@ extern "C" int dtk_pipeline_create(uint64_t slice_bytes, uint32_t slice_docs, ui
   dtk_pipeline *p = new dtk_pipeline();
   p->slice_bytes = slice_bytes;
   p->slice_docs = slice_docs;
+  if (hipStreamCreateWithFlags(&p->s_up, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&p->s_run, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&p->s_down, hipStreamNonBlocking) != hipSuccess) {
+    dtk_pipeline_free(p);
+    return DTK_E_HIP;
+  }
   for (uint32_t i = 0; i < depth; i++) {
     dtk_batch *b = nullptr;
-    const int rc = dtk_batch_create(slice_bytes, slice_docs, &b);
+    int rc = dtk_batch_create(slice_bytes, slice_docs, &b);
+    if (rc == DTK_OK) {
+      p->slots.push_back(b);
+      rc = dtk_batch_set_streams(b, p->s_run, p->s_up);
+      if (rc == DTK_OK) rc = dtk_batch_set_download_stream(b, p->s_down);
+    }
     if (rc != DTK_OK) { dtk_pipeline_free(p); return rc; }
-    p->slots.push_back(b);
   }
   p->first.assign(depth, 0);
   p->count.assign(depth, 0);
+  p->touched.assign(depth, 0);
   *out = p;
   return DTK_OK;
 }
@@ -50,6 +67,8 @@ extern "C" int dtk_pipeline_create(uint64_t slice_bytes, uint32_t slice_docs, ui
 extern "C" void dtk_pipeline_free(dtk_pipeline *p) {
   if (!p) return;
   for (dtk_batch *b : p->slots) dtk_batch_free(b);
+  for (hipStream_t st : {p->s_up, p->s_run, p->s_down})
+    if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
   delete p;
 }
 
@@ -62,12 +81,39 @@ extern "C" int dtk_pipeline_set_chunking(dtk_pipeline *p, uint32_t chunk_bytes, 
   return DTK_OK;
 }
 
+extern "C" int dtk_pipeline_set_result_fields(dtk_pipeline *p, uint32_t fields) {
+  if (!p) return DTK_E_ARG;
+  for (dtk_batch *b : p->slots) {
+    const int rc = dtk_batch_set_result_fields(b, fields ? fields : (uint32_t)DTK_R_ALL);
+    if (rc != DTK_OK) return rc;
+  }
+  p->fields = fields;
+  return DTK_OK;
+}
+
+// Slices whose kernels have finished start their way home now (nothing here blocks; the copies queue up on the download
+// stream in slice order): the download of slice i runs under the walk of slice i + 1 and the upload of slice i + 2.
+static void begin_downloads(dtk_pipeline *p, uint32_t oldest) {
+  if (!p->fields) return;
+  const uint32_t depth = (uint32_t)p->slots.size();
+  for (uint32_t q = 0; q < depth; q++) {
+    const uint32_t slot = (oldest + q) % depth;
+    if (p->count[slot] == 0) continue;
+    if (!dtk_batch_done(p->slots[slot])) break;
+    if (dtk_batch_download_begin(p->slots[slot]) != DTK_OK) break;  // (deliver() reports the error)
+  }
+}
+
 static int deliver(dtk_pipeline *p, uint32_t slot, dtk_slice_fn fn, void *user) {
   if (p->count[slot] == 0) return DTK_OK;
+  begin_downloads(p, slot);
   dtk_totals t;
   int rc = dtk_batch_totals(p->slots[slot], &t);  // waits for the slice; repairs, capacity check
+  if (rc == DTK_OK && p->fields) rc = dtk_batch_download_begin(p->slots[slot]);
+  begin_downloads(p, slot);  // (the next slices' copies behind this one's, before the callback waits for its own)
   const uint32_t first = p->first[slot], n = p->count[slot];
   p->count[slot] = 0;
+  p->touched[slot] = 0;
   if (rc != DTK_OK) return rc;
   return fn ? fn(user, first, n, p->slots[slot]) : DTK_OK;
 }
@@ -103,6 +149,7 @@ extern "C" int dtk_pipeline_run(dtk_pipeline *p, const dtk_model *m, const uint8
     if ((rc = deliver(p, slot, fn, user)) != DTK_OK) break;
     p->off.resize((size_t)(j - i) + 1);
     for (uint32_t d = i; d <= j; d++) p->off[d - i] = doc_off[d] - doc_off[i];
+    p->touched[slot] = 1;
     if ((rc = dtk_batch_set_input(p->slots[slot], text + doc_off[i], p->off.data(), j - i)) != DTK_OK) break;
     if ((rc = dtk_batch_run(m, p->slots[slot], flags)) != DTK_OK) break;
     p->first[slot] = i;
@@ -114,7 +161,8 @@ extern "C" int dtk_pipeline_run(dtk_pipeline *p, const dtk_model *m, const uint8
   for (uint32_t q = 0; q < depth; q++) {
     const uint32_t slot = (k + q) % depth;
     if (rc == DTK_OK) rc = deliver(p, slot, fn, user);
-    else if (p->count[slot]) { (void)dtk_batch_sync(p->slots[slot]); p->count[slot] = 0; }
+    // (an error: nothing is handed over any more, but no copy from the caller's text may outlive the call)
+    if (rc != DTK_OK && p->touched[slot]) { (void)dtk_batch_sync(p->slots[slot]); p->count[slot] = 0; p->touched[slot] = 0; }
   }
   if (registered) { (void)hipHostUnregister((void *)(text + doc_off[0])); (void)hipGetLastError(); }
   return rc;

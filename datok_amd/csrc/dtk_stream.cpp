@@ -9,6 +9,7 @@
 #include "../../include/datok.hpp"
 
 namespace {
+constexpr uint32_t kReplayFields = DTK_R_EVENTS | DTK_R_TOK_BYTE | DTK_R_CSR | DTK_R_STATUS;
 // One batch per calling thread, kept between calls (creating one costs a dozen device allocations and
 // a stream: milliseconds, far more than tokenizing a short string) and replaced when an input does
 // not fit.  dtk_transduce_release() frees it; so does the end of the thread.
@@ -32,12 +33,15 @@ struct BatchCache {
 thread_local BatchCache g_cache;
 
 // set_input + run on the cached batch; a batch made for another device is replaced once
-int run_cached(const dtk_model *m, const uint8_t *text, size_t n, uint32_t flags, dtk_batch **bp) {
+// fields != 0: these result arrays leave for the host inside the run (DTK_R_EAGER: one short stream needs no copy
+// engine set up seven times behind it)
+int run_cached(const dtk_model *m, const uint8_t *text, size_t n, uint32_t flags, dtk_batch **bp, uint32_t fields = 0) {
   const uint64_t off[2] = {0, (uint64_t)n};
   for (int attempt = 0; attempt < 2; attempt++) {
     int rc = g_cache.get(n ? n : 1, bp);
     if (rc != DTK_OK) return rc;
     if ((rc = dtk_batch_set_input(*bp, text, off, 1)) != DTK_OK) return rc;
+    if ((rc = dtk_batch_set_result_fields(*bp, fields ? (fields | DTK_R_EAGER) : (uint32_t)DTK_R_ALL)) != DTK_OK) return rc;
     rc = dtk_batch_run(m, *bp, flags);
     if (rc == DTK_E_ARG && attempt == 0) { g_cache.drop(); continue; }  // the model lives on another device
     return rc;
@@ -54,7 +58,9 @@ extern "C" int dtk_transduce_result(const dtk_model *m, const uint8_t *text, siz
                                     dtk_result_view *view) {
   if (!m || !view || (n && !text)) return DTK_E_ARG;
   dtk_batch *b = nullptr;
-  int rc = run_cached(m, text, n, flags & DTK_NEWLINE_AFTER_EOT, &b);
+  // what a closure replay reads (include/datok.hpp replay_view, datok_amd/host.py): the events, the tokens' byte
+  // ranges, the row offsets and the status -- the rune offset arrays stay on the device
+  int rc = run_cached(m, text, n, flags & DTK_NEWLINE_AFTER_EOT, &b, kReplayFields);
   if (rc != DTK_OK) return rc;
   return dtk_batch_result_host(b, view);
 }
@@ -92,7 +98,7 @@ extern "C" int dtk_transduce_replay(const dtk_model *m, const uint8_t *text, siz
   dtk_batch *b = nullptr;
   dtk_result_view v;
   int rc;
-  if ((rc = run_cached(m, text, n, bits & DTK_NEWLINE_AFTER_EOT, &b)) != DTK_OK ||
+  if ((rc = run_cached(m, text, n, bits & DTK_NEWLINE_AFTER_EOT, &b, kReplayFields)) != DTK_OK ||
       (rc = dtk_batch_result_host(b, &v)) != DTK_OK)
     return rc;
   std::ostringstream os;

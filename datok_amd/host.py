@@ -409,17 +409,31 @@ class Batch:
         data = C.string_at(v.bytes, v.total) if v.total else b""
         return data, off
 
-    def result(self) -> BatchResult:
+    # dtk_batch_set_result_fields (datok_gpu.h DTK_R_*)
+    R_CSR, R_TOK_RUNE, R_TOK_BYTE, R_SENT, R_TEXTS, R_STATUS, R_EVENTS, R_ALL = 1, 2, 4, 8, 16, 32, 64, 127
+
+    def set_result_fields(self, fields=R_ALL):
+        """Which arrays result() brings to the host (the others come back empty)."""
+        check(lib().dtk_batch_set_result_fields(self._h, int(fields)), "dtk_batch_set_result_fields")
+
+    def download_begin(self):
+        """Completes the run and starts the asynchronous copies of the selected arrays; result() waits for them."""
+        check(lib().dtk_batch_download_begin(self._h), "dtk_batch_download_begin")
+
+    def result(self, copy=True) -> BatchResult:
+        """The result arrays on the host (dtk_batch_result_host).  copy=False: views of the batch's page-locked
+        buffers, valid until its next run."""
         v = ResultView()
         check(lib().dtk_batch_result_host(self._h, C.byref(v)), "dtk_batch_result_host")
         t = self.totals()
         nd = self.n_docs
 
         def arr(ptr, n, dt):
-            if n == 0:
+            if n == 0 or not ptr:   # (an array that was not selected comes back NULL)
                 return np.zeros(0, dt)
             buf = (C.c_char * (n * np.dtype(dt).itemsize)).from_address(ptr)
-            return np.frombuffer(buf, dtype=dt).copy()
+            a = np.frombuffer(buf, dtype=dt)
+            return a.copy() if copy else a
         r = BatchResult()
         r.tok_off = arr(v.tok_off, nd + 1, np.uint64)
         r.sent_off = arr(v.sent_off, nd + 1, np.uint64)
@@ -432,7 +446,7 @@ class Batch:
         r.text_tok_end = arr(v.text_tok_end, t["n_texts"], np.uint32)
         r.text_sent_end = arr(v.text_sent_end, t["n_texts"], np.uint32)
         r.status = arr(v.status, nd, np.uint32)
-        r.ev_bits = arr(v.ev_bits, 5 * int(v.ev_words), np.uint32).reshape(5, -1)
+        r.ev_bits = arr(v.ev_bits, 5 * int(v.ev_words), np.uint32).reshape(5, -1) if v.ev_bits else np.zeros((5, 0), np.uint32)
         r.doc_tail = arr(v.doc_tail, nd, np.uint32)
         r.doc_off = self._doc_off
         r.exact = _exact_calls(v, arr)   # documents walked by the exact pass: id -> calls in order
@@ -482,6 +496,10 @@ class Pipeline:
     def set_chunking(self, chunk_bytes=0xFFFFFFFF, warm_bytes=16):
         check(lib().dtk_pipeline_set_chunking(self._h, int(chunk_bytes), int(warm_bytes)), "dtk_pipeline_set_chunking")
 
+    def set_result_fields(self, fields):
+        """Bring these result arrays (Batch.R_*) of every slice to the host, overlapped with the next slices' work."""
+        check(lib().dtk_pipeline_set_result_fields(self._h, int(fields)), "dtk_pipeline_set_result_fields")
+
     def run(self, tok, text: np.ndarray, doc_off: np.ndarray, flags=0, on_slice=None):
         text = np.ascontiguousarray(text, dtype=np.uint8)
         doc_off = np.ascontiguousarray(doc_off, dtype=np.uint64)
@@ -490,17 +508,20 @@ class Pipeline:
         def cb(_user, first, n, handle):
             if on_slice is None:
                 return 0
+            view = Batch.__new__(Batch)
             try:
-                view = Batch.__new__(Batch)
                 view._h = C.c_void_p(handle); view._keep = None; view.n_docs = int(n)
                 view._doc_off = (doc_off[first:first + n + 1] - doc_off[first]).astype(np.uint64)
                 view.total = int(view._doc_off[-1])
                 on_slice(int(first), int(n), view)
-                view._h = None      # the pipeline owns the batch
                 return 0
             except Exception as e:  # noqa: BLE001  (do not unwind through the C frame)
                 err.append(e)
                 return _lib.E_STATE
+            finally:
+                # the pipeline owns the batch: the view must never free it, also not when on_slice raised and the
+                # exception's traceback keeps the view alive (a double dtk_batch_free otherwise)
+                view._h = None
         fn = _lib.SLICE_FN(cb)
         rc = lib().dtk_pipeline_run(self._h, tok._h, text.ctypes.data, doc_off.ctypes.data, len(doc_off) - 1, flags, fn, None)
         if err:

@@ -153,6 +153,12 @@ int dtk_batch_set_warm_extend(dtk_batch *b, uint32_t max_bytes);
  * skips what only the device renderer needs. */
 int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags);
 int dtk_batch_sync(dtk_batch *b);
+/* Lend the batch HIP streams instead of the one it owns: `compute` for its kernels (NULL: keep), `upload` for the
+ * copies of dtk_batch_set_input (NULL: on the compute stream).  The batches of a dtk_pipeline share one of each: the
+ * HIP runtime has four hardware queues, streams that share one serialise, and a pipeline of any depth then needs three
+ * (uploads, kernels, downloads).  The streams must outlive the batch's use of them. */
+int dtk_batch_set_streams(dtk_batch *b, void *compute, void *upload);
+int dtk_batch_done(dtk_batch *b); /* 1 if everything dtk_batch_run enqueued has finished, 0 if not; never blocks */
 void *dtk_batch_stream(dtk_batch *b); /* hipStream_t, for event timing by the caller */
 
 /* Optional per-stage timing with HIP events recorded on the batch's stream
@@ -234,8 +240,38 @@ typedef struct {
 int dtk_batch_result_device(dtk_batch *b, dtk_result_view *out);
 /* status words of the first n documents, copied to the caller's array */
 int dtk_batch_status_host(dtk_batch *b, uint32_t *status, uint32_t n);
-/* Copies the arrays to host memory owned by the batch (valid until the next
- * run / free) and returns host pointers in the same struct. */
+/* The results on the host.  The reference hands every token to a host closure (matrix.go:528,569,677 -> w.Token,
+ * token_writer.go:72-88); here the arrays come over in one chain of asynchronous copies into page-locked memory owned
+ * by the batch, on a HIP stream of their own (the batch's stream and the upload direction of the link stay free).
+ *   dtk_batch_set_result_fields: which arrays a caller wants (DTK_R_*, default all): a caller that only reads the
+ *       rune offsets moves 1.1 B per input byte instead of 2.8; one that replays the events into closures needs
+ *       DTK_R_EVENTS | DTK_R_TOK_BYTE | DTK_R_CSR | DTK_R_STATUS.
+ *   dtk_batch_download_begin: completes the run like dtk_batch_totals, enqueues the copies and returns at once
+ *       (dtk_pipeline uses it to bring slice i home under the walk of slice i + 1 and the upload of slice i + 2).
+ *   dtk_batch_result_host: begins the download if nobody has, waits for it, and returns host pointers (valid until the
+ *       batch's next run / free); arrays that were not selected are NULL. */
+enum {
+  DTK_R_CSR = 1,       /* tok_off, sent_off, text_off */
+  DTK_R_TOK_RUNE = 2,  /* tok_rstart, tok_rend */
+  DTK_R_TOK_BYTE = 4,  /* tok_bstart, tok_bend */
+  DTK_R_SENT = 8,      /* sent */
+  DTK_R_TEXTS = 16,    /* text_tok_end, text_sent_end */
+  DTK_R_STATUS = 32,   /* status */
+  DTK_R_EVENTS = 64,   /* ev_bits, doc_tail */
+  DTK_R_ALL = 127,
+  /* with any of the above: the selected arrays leave for the host inside dtk_batch_run -- a kernel behind the
+   * compaction reads the row counts on the device and streams the rows into the batch's page-locked buffers, so no
+   * host round trip stands between the walk and the copy.  dtk_batch_result_host then finds them there (a run that
+   * needed a repair round, larger arrays or the exact pass copies again by itself). */
+  DTK_R_EAGER = 256
+};
+int dtk_batch_set_result_fields(dtk_batch *b, uint32_t fields);
+int dtk_batch_download_begin(dtk_batch *b);
+/* The HIP stream the result copies run on: the batch creates one with its first download; a caller with several
+ * batches should lend them one stream between them (dtk_pipeline does): the HIP runtime maps streams onto four
+ * hardware queues, and two streams on one queue serialise. */
+int dtk_batch_set_download_stream(dtk_batch *b, void *hip_stream);
+void *dtk_batch_download_stream(dtk_batch *b);
 int dtk_batch_result_host(dtk_batch *b, dtk_result_view *out);
 
 /* bit of position 0 of document d in the bitmaps of dtk_result_view.ev_bits */
@@ -280,6 +316,10 @@ typedef int (*dtk_slice_fn)(void *user, uint32_t first_doc, uint32_t n_docs, dtk
 int dtk_pipeline_create(uint64_t slice_bytes, uint32_t slice_docs, uint32_t depth, dtk_pipeline **out);
 void dtk_pipeline_free(dtk_pipeline *p);
 int dtk_pipeline_set_chunking(dtk_pipeline *p, uint32_t chunk_bytes, uint32_t warm_bytes);
+/* fields != 0 (DTK_R_*): every slice's selected result arrays are brought to the host -- the copies of slice i start as
+ * soon as its kernels have finished and run under the walk of slice i + 1 and the upload of slice i + 2; `fn` finds them
+ * through dtk_batch_result_host.  0 (the default): results stay in HBM unless fn asks. */
+int dtk_pipeline_set_result_fields(dtk_pipeline *p, uint32_t fields);
 int dtk_pipeline_run(dtk_pipeline *p, const dtk_model *m, const uint8_t *text, const uint64_t *doc_off,
                      uint32_t n_docs, uint32_t flags, dtk_slice_fn fn, void *user);
 void *dtk_pinned_alloc(size_t n); /* page-locked host memory (hipHostMalloc); NULL on failure */

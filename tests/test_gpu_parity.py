@@ -9,7 +9,7 @@ import pytest
 
 from conftest import MODELS, ROOT
 from goldens import failed_checks, golden_strings, load_cases, model_file
-from parity import assert_batch_equals_oracle
+from parity import assert_batch_equals_oracle, oracle_doc
 
 pytestmark = pytest.mark.gpu
 
@@ -604,7 +604,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import datok_amd
 from datok_amd import corpus
 from oracle import oracle as O
-from parity import assert_batch_equals_oracle
+from parity import assert_batch_equals_oracle, oracle_doc
 M = os.path.join(ROOT, "tests", "golden", "models")
 for name, (text, off) in (("tokenizer_de.matok", corpus.german_docs(96, 4096, seed=11)),
                           ("tokenizer_en.matok", corpus.english_zipf_docs(64, seed=12, max_bytes=8192)),
@@ -806,8 +806,8 @@ def test_round1_soak_failure_stays_fixed(gpu, oracle_models):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("pinned", [True, False])
-def test_pipeline_slices_equal_the_oracle(gpu, oracle_models, pinned):
+@pytest.mark.parametrize("pinned,prefetch", [(True, 0), (False, 0), (True, 127)])
+def test_pipeline_slices_equal_the_oracle(gpu, oracle_models, pinned, prefetch):
     """dtk_pipeline: a ragged corpus cut into slices at document boundaries (by bytes and by document count), three
     batches in turn, uploads from page-locked memory (dtk_pinned_alloc) or from ordinary memory (page-locked for the
     call): every slice arrives in order, covers its documents exactly, and every document equals the oracle."""
@@ -834,6 +834,8 @@ def test_pipeline_slices_equal_the_oracle(gpu, oracle_models, pinned):
         sub = text[int(off[first]):int(off[first + n])]
         assert_batch_equals_oracle(om, res, sub, sub_off, docs=range(0, n, 5))
     with datok_amd.Pipeline(1 << 20, 400, depth=3) as p:
+        if prefetch:  # every slice's arrays come to the host under the next slices' work (dtk_pipeline_set_result_fields)
+            p.set_result_fields(prefetch)
         p.run(tok, src, off, 0, on_slice)
         assert seen[-1][0] + seen[-1][1] == 3000 and len(seen) >= 8
         assert all(n <= 400 for _, n in seen)
@@ -843,3 +845,66 @@ def test_pipeline_slices_equal_the_oracle(gpu, oracle_models, pinned):
         p.run(tok, src[:int(off[100])], off[:101], 0, None)
     if buf is not None:
         buf.close()
+
+
+@pytest.mark.gpu
+def test_result_fields_select_what_comes_to_the_host(gpu, oracle_models):
+    """dtk_batch_set_result_fields: only the selected arrays are copied (page-locked buffers, asynchronous chain on the
+    batch's download stream); what was not selected comes back NULL / empty; a later, wider selection for the same run
+    fetches the rest; a new run starts afresh."""
+    import datok_amd
+    from datok_amd import corpus
+    B = datok_amd.Batch
+    text, off = corpus.german_docs(300, 1500, seed=21)
+    tok, om = gpu("tokenizer_de.matok"), oracle_models("tokenizer_de.matok")
+    with B(len(text), 300) as b:
+        b.set_input(text, off)
+        b.run(tok, 0)
+        b.set_result_fields(B.R_TOK_RUNE | B.R_SENT | B.R_CSR | B.R_STATUS)
+        b.download_begin()
+        r = b.result()
+        assert len(r.tok_rstart) == b.totals()["n_tokens"] and len(r.tok_bstart) == 0 and r.ev_bits.shape[1] == 0
+        assert len(r.text_tok_end) == 0 and len(r.status) == 300
+        for d in range(0, 300, 7):
+            exp = oracle_doc(om, text[int(off[d]):int(off[d + 1])].tobytes())
+            a, e = int(r.tok_off[d]), int(r.tok_off[d + 1])
+            assert np.array_equal(r.tok_rstart[a:e], exp["tok_rstart"]) and np.array_equal(r.tok_rend[a:e], exp["tok_rend"])
+            s0, s1 = int(r.sent_off[d]), int(r.sent_off[d + 1])
+            assert np.array_equal(r.sent[s0:s1], exp["sent"])
+        b.set_result_fields(B.R_ALL)            # the same run, everything: the missing arrays are fetched now
+        assert_batch_equals_oracle(om, b.result(), text, off, docs=range(0, 300, 11))
+        views = b.result(copy=False)            # views of the page-locked buffers themselves
+        assert views.tok_rstart.flags["OWNDATA"] is False and np.array_equal(views.tok_rstart, r.tok_rstart)
+        b.set_result_fields(B.R_EVENTS | B.R_TOK_BYTE | B.R_CSR | B.R_STATUS)   # what a closure replay needs
+        text2, off2 = corpus.german_docs(200, 900, seed=22)
+        b.set_input(text2, off2)
+        b.run(tok, 0)
+        r2 = b.result()
+        assert len(r2.tok_rstart) == 0 and len(r2.tok_bstart) == b.totals()["n_tokens"] and r2.ev_bits.shape[1] > 0
+        for d in (0, 57, 199):
+            exp = oracle_doc(om, text2[int(off2[d]):int(off2[d + 1])].tobytes())
+            a, e = int(r2.tok_off[d]), int(r2.tok_off[d + 1])
+            assert np.array_equal(r2.tok_bstart[a:e], exp["tok_bstart"]) and np.array_equal(r2.tok_bend[a:e], exp["tok_bend"])
+
+
+@pytest.mark.gpu
+def test_pipeline_survives_a_failing_callback(gpu):
+    """a callback that raises must not leave a Batch view that owns the pipeline's batch (the view's
+    __del__ would free it a second time).  The pipeline is used again and closed afterwards."""
+    import datok_amd
+    from datok_amd import corpus
+    text, off = corpus.german_docs(64, 2048, seed=5)
+    tok = gpu("tokenizer_de.matok")
+    kept = []
+
+    def bad(first, n, b):
+        kept.append(b)  # (keeps the view alive beyond the callback, as a traceback would)
+        raise RuntimeError("boom")
+    with datok_amd.Pipeline(32 << 10, 16, depth=3) as p:
+        with pytest.raises(RuntimeError):
+            p.run(tok, text, off, 0, bad)
+        assert kept[0]._h is None
+        kept.clear()
+        seen = []
+        p.run(tok, text, off, 0, lambda first, n, b: seen.append(b.totals()["n_tokens"]))
+        assert len(seen) == 4 and all(seen)
