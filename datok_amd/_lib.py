@@ -29,6 +29,7 @@ EXPORTS = [
     "dtk_pinned_alloc", "dtk_pinned_free",
     "dtk_batch_set_result_fields", "dtk_batch_download_begin", "dtk_pipeline_set_result_fields",
     "dtk_batch_set_download_stream", "dtk_batch_download_stream", "dtk_batch_done", "dtk_batch_set_streams",
+    "dtk_debug_configure",
 ]
 
 
@@ -160,6 +161,12 @@ def lib():
     L.dtk_pinned_alloc.argtypes = [sz]
     L.dtk_pinned_free.argtypes = [vp]
     L.dtk_pinned_free.restype = None
+    # Test hooks: the library itself never reads the environment; this harness forwards the DATOK_* switches the tests
+    # and scripts set (dtk_debug_configure; unknown names are not the library's and are left alone).
+    L.dtk_debug_configure.argtypes = [C.c_char_p, C.c_char_p]
+    for k, v in os.environ.items():
+        if k.startswith("DATOK_") and k not in ("DATOK_GPU_LIB", "DATOK_GATHER_TIMEOUT"):
+            L.dtk_debug_configure(k.encode(), v.encode())
     _lib = L
     return L
 

@@ -59,6 +59,53 @@ extern "C" int dtk_set_device(int device) {
   return DTK_OK;
 }
 
+// ---------------------------------------------------------------- test hooks
+//
+// The library's behaviour does not depend on the caller's environment: nothing here reads it.  The switches
+// below select code paths that the library otherwise picks by model, shape or history, so that the tests can run the
+// whole suite over each of them; only dtk_debug_configure sets them (the Python harness forwards DATOK_* variables
+// to it, datok_amd/_lib.py -- the shipped entry points never look).  None of them changes a result.
+struct DtkDebug {
+  int sym16 = 0;         // 16-bit stream entries (and the general loop) although the model's entries fit a code table
+  int force_wide = 0;    // 32-bit plain cells for any model (MatrixTrans<uint32_t>)
+  int file_columns = 0;  // keep the file's column order
+  int no_fused = 0;      // plain uint16 cells: no fused epsilon + rune cells
+  int plain_walk = 0;    // the general loop for a model the lean loop would serve
+  int no_dense = 0;      // walk a double array's {base, check} pairs instead of its dense layout
+  int small_max = -1;    // documents of at most this many bytes are compacted one per lane (-1: by batch shape)
+  int warm_ws = 0, warm_min = 0;  // warm-up start behind the n-th run of blanks (0: off)
+  int warm_extend = -1;  // overrides dtk_batch_set_warm_extend (-1: do not)
+  int lds_bits = 1;      // 0: event bits straight to memory
+  int split_start = 0;   // start records and chunk walk as two launches
+  int dev_rounds = -1;   // repair rounds enqueued with every run (-1: two after a run that had to repair)
+  int compact_full = 0;  // both compaction kernels with every run
+  int clear_kernel = 0;  // the accumulator block is cleared by k_clear2, not by k_symbolize's blocks
+  int round_limit = -1;  // host repair rounds before the one-lane-per-document fallback (-1: the longest document's lanes)
+  int debug_repair = 0;  // print the lane records of documents that stay broken
+  int exp_skip = 0;      // (DTK_EXPERIMENTS builds) stages skipped from the second run on
+};
+static DtkDebug g_dbg;
+
+extern "C" int dtk_debug_configure(const char *key, const char *value) {
+  if (!key) return DTK_E_ARG;
+  const int v = value ? atoi(value) : 1;
+  const struct { const char *name; int *field; bool flag; } tab[] = {
+      {"SYM16", &g_dbg.sym16, true}, {"FORCE_WIDE", &g_dbg.force_wide, true}, {"FILE_COLUMNS", &g_dbg.file_columns, true},
+      {"NO_FUSED", &g_dbg.no_fused, true}, {"PLAIN_WALK", &g_dbg.plain_walk, true}, {"NO_DENSE", &g_dbg.no_dense, true},
+      {"SMALL_MAX", &g_dbg.small_max, false}, {"WARM_WS", &g_dbg.warm_ws, false}, {"WARM_MIN", &g_dbg.warm_min, false},
+      {"WARM_EXTEND", &g_dbg.warm_extend, false}, {"LDS_BITS", &g_dbg.lds_bits, false}, {"SPLIT_START", &g_dbg.split_start, false},
+      {"DEV_ROUNDS", &g_dbg.dev_rounds, false}, {"COMPACT_FULL", &g_dbg.compact_full, true}, {"CLEAR_KERNEL", &g_dbg.clear_kernel, true},
+      {"ROUND_LIMIT", &g_dbg.round_limit, false}, {"DEBUG_REPAIR", &g_dbg.debug_repair, true}, {"EXP_SKIP", &g_dbg.exp_skip, false}};
+  if (strncmp(key, "DATOK_", 6) == 0) key += 6;
+  for (const auto &e : tab)
+    if (strcmp(key, e.name) == 0) {
+      // (a flag is on by being named, as the environment variables were: `DATOK_NO_FUSED=` or `=1` both switch it on)
+      *e.field = e.flag ? ((value && value[0] == '0' && value[1] == 0) ? 0 : 1) : v;
+      return DTK_OK;
+    }
+  return DTK_E_ARG;
+}
+
 // ------------------------------------------------------------------- model
 
 struct dtk_model {
@@ -223,7 +270,7 @@ static int upload(dtk_model *m, const void *tab, size_t tab_bytes) {
       m->sig.code_ident[w] = code_of((ident & DTK_SYM_MASK) | (3u << DTK_SYM_CLS_SHIFT) | (w << DTK_SYM_W_SHIFT));
     m->sig.code_ident[0] = DTK_SYM_CONT;
     m->sig.code_fffd1 = code_of(fffd | (1u << DTK_SYM_W_SHIFT));  // an invalid byte decodes to U+FFFD, one byte wide
-    m->sig.n_codes = (fits && !getenv("DATOK_SYM16")) ? (uint32_t)entries.size() : 0u;
+    m->sig.n_codes = (fits && !g_dbg.sym16) ? (uint32_t)entries.size() : 0u;
     entries.resize(256, 0);  // (DTK_SYM_CONT and the unused codes: width 0)
     HIP_TRY(hipMalloc(&m->d_codes, 512 + bytes.size()));
     HIP_TRY(hipMemcpy(m->d_codes, entries.data(), 512, hipMemcpyHostToDevice));
@@ -319,7 +366,7 @@ static int layout_matrix(dtk_model *m, const std::vector<uint32_t> &arr, uint64_
 
   // 32-bit cells for automata with 32767 states or more; DATOK_FORCE_WIDE=1 selects them for any
   // model (no shipped model is that large: this is how the tests reach MatrixTrans<uint32_t>)
-  const bool wide = (N + 1) > 0x7FFFu || getenv("DATOK_FORCE_WIDE") != nullptr;
+  const bool wide = (N + 1) > 0x7FFFu || g_dbg.force_wide;
   const uint32_t stride = (uint32_t)((S + 7) & ~7ull);
   const size_t cells_total = (size_t)(N + 1) * stride;
   // Columns: the symbols of running text first -- blank, the lower-case letters by frequency, full stop, comma,
@@ -336,7 +383,7 @@ static int layout_matrix(dtk_model *m, const std::vector<uint32_t> &arr, uint64_
                                      '/', '\t', '\r'};
     uint32_t next_col = 1;
     col[0] = 0;
-    if (!getenv("DATOK_FILE_COLUMNS"))
+    if (!g_dbg.file_columns)
       for (uint32_t r : order)
         for (size_t i = 0; i < m->sigma_runes.size(); i++)
           if (m->sigma_runes[i] == r) {
@@ -348,7 +395,7 @@ static int layout_matrix(dtk_model *m, const std::vector<uint32_t> &arr, uint64_
   }
   // 15-bit state ids: uint32 cells with fused epsilon+rune entries (MatrixFusedTrans);
   // DATOK_NO_FUSED=1 keeps the plain uint16 table (for A/B measurements)
-  const bool fused = !wide && !getenv("DATOK_NO_FUSED");
+  const bool fused = !wide && !g_dbg.no_fused;
   const size_t cell_bytes = (wide || fused) ? 4 : 2;
   std::vector<uint8_t> host(cells_total * cell_bytes, 0);
   auto put = [&](size_t at, uint32_t v) {
@@ -387,7 +434,7 @@ static int layout_matrix(dtk_model *m, const std::vector<uint32_t> &arr, uint64_
   m->tab.entry_bytes = (uint32_t)cell_bytes;
   m->tab.fused = fused ? 1u : 0u;
   m->tab.ident_guard = m->unknown_used ? (uint32_t)m->identity : 0xFFFFFFFFu;
-  m->tab.plain_walk = getenv("DATOK_PLAIN_WALK") ? 1u : 0u;
+  m->tab.plain_walk = g_dbg.plain_walk ? 1u : 0u;
   m->tab.da_dense = da_dense ? 1u : 0u;
   m->tab.stride = stride;
   m->tab.n_states = (uint32_t)N;
@@ -462,7 +509,7 @@ static int build_datok(dtk_model *m, const std::vector<uint8_t> &raw) {
   // path set).
   // (only with fused cells: the lean loop and the fused general loop carry the double array's EOT rules; the plain
   //  matrix encodings that DATOK_NO_FUSED / DATOK_FORCE_WIDE select for the tests are not run with them)
-  if (!getenv("DATOK_NO_DENSE") && !getenv("DATOK_NO_FUSED") && !getenv("DATOK_FORCE_WIDE")) {
+  if (!g_dbg.no_dense && !g_dbg.no_fused && !g_dbg.force_wide) {
     std::vector<uint32_t> arr;
     uint64_t n_dense = 0;
     // one step of datok.go:888-901 + 1055-1063 from state s0 on symbol a: 0 = no arc, else target | FIRSTBIT if
@@ -1102,7 +1149,7 @@ extern "C" int dtk_batch_create(uint64_t max_bytes, uint32_t max_docs, dtk_batch
   } while (0)
   B_TRY(hipGetDevice(&b->device));
   B_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
-  if (const char *e = getenv("DATOK_ROUND_LIMIT")) b->round_limit = (uint32_t)atoi(e);
+  if (g_dbg.round_limit >= 0) b->round_limit = (uint32_t)g_dbg.round_limit;
   const uint64_t pad = 256;
   B_TRY(hipMalloc((void **)&b->d_text_own, max_bytes + pad));
   B_TRY(hipMalloc((void **)&b->d_off_own, ((uint64_t)max_docs + 1) * 8));
@@ -1280,9 +1327,9 @@ static int plan_lanes(dtk_batch *b) {
     // One lane per document pays for many tiny documents (tweets, single sentences): 64-byte documents compact five
     // times faster that way.  From 256 bytes on the lanes' scattered row stores cost more than a wave per document
     // (measured: 256 B 245 -> 274 us, 1 KiB 81 -> 282 us per 32 MiB), hence the low limit.
-    static const char *e_sm = getenv("DATOK_SMALL_MAX");
+    const bool e_sm = g_dbg.small_max >= 0;
     uint32_t sm = b->n_docs >= 2048u ? 160u : 0u;
-    if (e_sm) sm = (uint32_t)atoi(e_sm);
+    if (e_sm) sm = (uint32_t)g_dbg.small_max;
     std::vector<uint32_t> big;
     if (sm)
       for (uint32_t d = 0; d < b->n_docs; d++)
@@ -1403,15 +1450,11 @@ static DtkSpecArgs spec_args(dtk_batch *b, bool redo) {
   s.redo_from = redo ? b->d_redo : nullptr;
   s.text = b->d_text;
   {
-    static const char *e = getenv("DATOK_WARM_WS");
-    s.warm_ws = e ? (uint32_t)atoi(e) : 0u;
-    static const char *e2 = getenv("DATOK_WARM_MIN");
-    s.warm_min = e2 ? (uint32_t)atoi(e2) : 0u;
-    static const char *e5 = getenv("DATOK_WARM_EXTEND");
-    s.warm_extend = e5 ? (uint32_t)atoi(e5) : b->cfg_extend;
-    // the walk collects its event bits in LDS, one set of bitmaps per wave (DATOK_LDS_BITS=0: straight to memory)
-    static const char *e3 = getenv("DATOK_LDS_BITS");
-    const bool lds = e3 ? atoi(e3) != 0 : true;
+    s.warm_ws = (uint32_t)g_dbg.warm_ws;
+    s.warm_min = (uint32_t)g_dbg.warm_min;
+    s.warm_extend = g_dbg.warm_extend >= 0 ? (uint32_t)g_dbg.warm_extend : b->cfg_extend;
+    // the walk collects its event bits in LDS, one set of bitmaps per wave (test hook LDS_BITS=0: straight to memory)
+    const bool lds = g_dbg.lds_bits != 0;
     s.lds_words = (lds && b->chunk <= DTK_LDS_BIT_CHUNK_MAX) ? DTK_LDS_BIT_WORDS(b->chunk) : 0u;
   }
   return s;
@@ -1487,7 +1530,7 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
 #ifdef DTK_EXPERIMENTS
   // knock-out timing (scripts/knockout.sh): from the second run on, skip the stages named by the
   // bit mask; with an unchanged input their outputs of the first run are still valid
-  static const int exp_skip = getenv("DATOK_EXP_SKIP") ? atoi(getenv("DATOK_EXP_SKIP")) : 0;
+  const int exp_skip = g_dbg.exp_skip;
   const int skip = b->exp_runs++ > 0 ? exp_skip : 0;
 #else
   const int skip = 0;
@@ -1516,7 +1559,7 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
     // ... and the accumulator block too, once it has been cleared whole (totals[6], which k_symbolize's own blocks
     // write, is left out there: it holds the number of the last run that saw invalid UTF-8)
     fold_acc = fold && b->acc_primed && acc_used / 16 < 0xFFFFFFFFull &&
-               !getenv("DATOK_CLEAR_KERNEL");
+               !g_dbg.clear_kernel;
     if (!fold_acc) {
       if (dtk_launch_clear2(b->d_acc, acc_used, b->d_bits, (fold || (skip & 4)) ? 0 : (size_t)EVB_KINDS * b->bit_words * 4, s))
         return hip_fail(hipGetLastError(), "clear");
@@ -1542,14 +1585,13 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
     sp_first = sp;
     uint32_t *nb = (uint32_t *)(b->d_totals + 8);  // nb[0]: broken documents after the first pass, nb[r + 1]: after round r
     // DATOK_SPLIT_START=1: start records and chunk walk as two launches (the repair rounds' kernels)
-    static const bool split_env = getenv("DATOK_SPLIT_START") && atoi(getenv("DATOK_SPLIT_START")) != 0;
+    const bool split_env = g_dbg.split_start != 0;
     const bool split = split_env || sp.lds_words == 0;  // (k_spec_both reports through the wave's LDS bitmaps)
     // Device-side repair: if the batch's last run had to repair (text with tags, say), two repair rounds are
     // enqueued right behind the first pass; their kernels return at once when the verification before them found
     // nothing broken, and the scan / compaction behind them only run once nothing is.  A miss then costs no host
     // round trip.  (Not done blindly: ten empty launches cost a clean corpus some 15 us per batch.)
-    static const char *e_dr = getenv("DATOK_DEV_ROUNDS");
-    b->dev_rounds = e_dr ? (uint32_t)atoi(e_dr) : (b->expect_repairs ? 2u : 0u);
+    b->dev_rounds = g_dbg.dev_rounds >= 0 ? (uint32_t)g_dbg.dev_rounds : (b->expect_repairs ? 2u : 0u);
     if (b->dev_rounds > 3u) b->dev_rounds = 3u;
     fix_in_scan = b->n_docs <= 8192u && b->dev_rounds == 0;  // k_spec_fix's step rides in the one-block scan kernel
     for (int stage = 0; stage < 5; stage++) {
@@ -1584,7 +1626,7 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
   // (the kernel for documents with EOT calls only if this batch object's last run had such documents; finish()
   //  launches it when the other kernel reports one after all)
   b->ran_full = false;
-  static const bool eager_full = getenv("DATOK_COMPACT_FULL") != nullptr;  // (tests: both kernels with every run)
+  const bool eager_full = g_dbg.compact_full != 0;  // (tests: both kernels with every run)
   int rc = (skip & 8) ? DTK_OK : launch_compact2(b, (b->expect_eot || eager_full) ? 3 : 1);
   if (rc != DTK_OK) return rc;
   STAGE(9);
@@ -1732,7 +1774,7 @@ static int finish(dtk_batch *b) {
         if (rc != DTK_OK) return rc;
         HIP_TRY(hipMemcpyAsync(&left, n_bad, 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        if (left != 0 && getenv("DATOK_DEBUG_REPAIR") && b->repair_rounds < 12) {
+        if (left != 0 && g_dbg.debug_repair && b->repair_rounds < 12) {
           std::vector<uint32_t> redo(b->n_docs), chunk_off(b->n_docs + 1);
           HIP_TRY(hipMemcpy(redo.data(), b->d_redo, (size_t)b->n_docs * 4, hipMemcpyDeviceToHost));
           HIP_TRY(hipMemcpy(chunk_off.data(), b->d_chunk_off, ((size_t)b->n_docs + 1) * 4, hipMemcpyDeviceToHost));

@@ -2918,11 +2918,8 @@ __global__ __launch_bounds__(WAVE) void k_to_host(DtkToHostArgs A) {
   if (blockIdx.x == 0 && lane == 0) *A.done = A.epoch;
 }
 
-static uint32_t g_tohost_waves = DTK_TOHOST_WAVES;
-extern "C" void dtk_debug_set_tohost_waves(uint32_t n) { g_tohost_waves = n ? n : DTK_TOHOST_WAVES; }
-
 extern "C" int dtk_launch_to_host(const DtkToHostArgs *args, void *stream) {
-  hipLaunchKernelGGL(k_to_host, dim3(g_tohost_waves), dim3(WAVE), 0, (hipStream_t)stream, *args);
+  hipLaunchKernelGGL(k_to_host, dim3(DTK_TOHOST_WAVES), dim3(WAVE), 0, (hipStream_t)stream, *args);
   return (int)hipGetLastError();
 }
 

@@ -80,6 +80,14 @@ int dtk_set_device(int device);          /* device used by subsequent loads / ba
 const char *dtk_strerror(int code);
 const char *dtk_last_hip_error(void);
 
+/* Test hook.  The library never reads the environment; the code paths it otherwise picks by model, batch shape or
+ * history (general loop instead of the lean one, 16-bit stream entries, the double array's pairs instead of its
+ * dense layout, two-launch first pass, ...) can be forced through this call so that the test suite runs over each
+ * of them.  key: the name in dtk_host.cpp's table, with or without the "DATOK_" prefix the tests' environment
+ * variables carry (datok_amd/_lib.py forwards those); value: an integer as text (NULL = 1).  No switch changes a
+ * result.  Set before the models / batches it should affect are created. */
+int dtk_debug_configure(const char *key, const char *value);
+
 /* ---- model: replaces LoadTokenizerFile (fomafile.go:452-484), LoadMatrixFile
  *      (matrix.go:214-231), LoadDatokFile (datok.go:600-617).  gunzip, sniff
  *      "MATOK"/"DATOK", parse, build the device tables.  Immutable afterwards,

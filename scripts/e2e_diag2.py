@@ -23,8 +23,6 @@ CASES = ((0, 3), (B.R_TOK_RUNE | B.R_SENT | B.R_CSR | B.R_STATUS, 3), (B.R_TOK_R
 if os.environ.get("E2E_ONLY"):
     CASES = ((B.R_TOK_RUNE | B.R_SENT | B.R_CSR | B.R_STATUS, 3),)
 import ctypes
-if os.environ.get("TOHOST_WAVES"):
-    datok_amd.lib().dtk_debug_set_tohost_waves(ctypes.c_uint32(int(os.environ["TOHOST_WAVES"])))
 if os.environ.get("E2E_CASES"):
     CASES = tuple((B.R_TOK_RUNE | B.R_SENT | B.R_CSR | B.R_STATUS, int(d)) for d in os.environ["E2E_CASES"].split(","))
 for fields, depth in CASES:

@@ -61,3 +61,19 @@ def test_error_strings_and_constants():
         assert L.dtk_strerror(code)
     assert (datok_amd.TOKENS, datok_amd.SENTENCES, datok_amd.TOKEN_POS, datok_amd.SENTENCE_POS,
             datok_amd.NEWLINE_AFTER_EOT, datok_amd.SIMPLE) == (1, 2, 4, 8, 16, 3)   # token_writer.go:17-25
+
+
+def test_library_never_reads_the_environment():
+    """kernel selection of a shipped library must not depend on the caller's environment.  No getenv in the
+    native sources; the test hooks go through dtk_debug_configure (which this harness feeds from DATOK_* variables)."""
+    for base in (os.path.join("datok_amd", "csrc"), "include"):
+        for f in os.listdir(os.path.join(ROOT, base)):
+            if f.endswith((".cpp", ".hip", ".h", ".hpp")):
+                txt = open(os.path.join(ROOT, base, f), encoding="utf-8", errors="replace").read()
+                assert "getenv" not in txt, f
+    import datok_amd
+    from datok_amd import _lib
+    L = datok_amd.lib()
+    assert L.dtk_debug_configure(b"DATOK_NO_SUCH_SWITCH", b"1") == _lib.E_ARG
+    assert L.dtk_debug_configure(b"WARM_WS", b"0") == _lib.OK          # (its default: nothing changes)
+    assert L.dtk_debug_configure(b"DATOK_WARM_MIN", b"0") == _lib.OK
