@@ -1,5 +1,5 @@
 // dtk_host.cpp -- host side of libdatok_gpu.so: model files, device tables,
-// batch plumbing.  Everything that computes runs in dtk_kernels.hip; nothing
+// batch plumbing.  Everything that computes runs in the .hip units (symbolize, walk, repair, compact, render); nothing
 // here walks the automaton.
 #include <hip/hip_runtime.h>
 #include <zlib.h>

@@ -321,7 +321,7 @@ struct DtkToHostArgs {
 extern "C" {
 #endif
 int dtk_launch_to_host(const struct DtkToHostArgs *args, void *stream);
-// launchers (dtk_kernels.hip); stream is a hipStream_t
+// launchers (dtk_symbolize / dtk_walk / dtk_repair / dtk_compact .hip); stream is a hipStream_t
 int dtk_launch_symbolize(const uint8_t *text, const uint64_t *doc_off, uint32_t n_docs,
                          uint64_t total, const struct DtkSigmaDev *sig, void *sym, int padded,
                          const uint32_t *blk_doc, unsigned long long *n_invalid, uint32_t *rs_bits,
@@ -333,6 +333,8 @@ int dtk_launch_walk(const struct DtkTableDev *tab, const struct DtkWalkArgs *arg
 int dtk_launch_spec(const struct DtkTableDev *tab, const struct DtkWalkArgs *args,
                     const struct DtkSpecArgs *spec, int stage, uint32_t cmp_mask, uint32_t *redo_out,
                     uint32_t *n_bad, void *stream);
+int dtk_launch_spec_check(const struct DtkWalkArgs *args, const struct DtkSpecArgs *spec, int stage, uint32_t cmp_mask,
+                          uint32_t *redo_out, uint32_t *n_bad, void *stream);
 int dtk_launch_redo_clear(const struct DtkWalkArgs *args, const struct DtkSpecArgs *spec, void *stream);
 int dtk_launch_compact(const struct DtkCompactArgs *args, uint32_t small_max, const uint32_t *big_docs, uint32_t n_big,
                        int which, void *stream);
