@@ -18,9 +18,10 @@ HIP kernels behind the C-ABI of libdatok_gpu.so (include/datok_gpu.h):
     `datok convert --double-array`       foma_to_datok(bytes) -> bytes        (datok.go:82-238)
     --                                   Batch: many documents per launch (addition)
     --                                   Pipeline: a corpus larger than a batch, uploads overlapped (addition)
+    --                                   MultiPipeline: ... sharded over several GPUs of a node (addition)
 """
 from ._lib import (DatokGpuError, ST_BAD_MODEL, ST_BAD_OFFSET, ST_EMPTY_TEXT, ST_IRREGULAR, ST_STEP_LIMIT,  # noqa: F401
                    ST_WINDOW_OVERFLOW, build, lib)
 from .host import (NEWLINE_AFTER_EOT, SENTENCE_POS, SENTENCES, SIMPLE, TOKEN_POS, TOKENS, Batch,  # noqa: F401
-                   BatchResult, PinnedBuffer, Pipeline, TokenWriter, Tokenizer, foma_to_datok, foma_to_matok, load_foma_file,
+                   BatchResult, MultiPipeline, PinnedBuffer, Pipeline, TokenWriter, Tokenizer, foma_to_datok, foma_to_matok, load_foma_file,
                    load_tokenizer_file, new_token_writer, replay)

@@ -30,6 +30,7 @@ EXPORTS = [
     "dtk_batch_set_result_fields", "dtk_batch_download_begin", "dtk_pipeline_set_result_fields",
     "dtk_batch_set_download_stream", "dtk_batch_download_stream", "dtk_batch_done", "dtk_batch_set_streams",
     "dtk_debug_configure",
+    "dtk_multi_create", "dtk_multi_free", "dtk_multi_type", "dtk_multi_set_result_fields", "dtk_multi_set_chunking", "dtk_multi_run",
 ]
 
 
@@ -157,6 +158,14 @@ def lib():
     L.dtk_pipeline_free.restype = None
     L.dtk_pipeline_set_chunking.argtypes = [vp, u32, u32]
     L.dtk_pipeline_run.argtypes = [vp, vp, vp, vp, u32, u32, SLICE_FN, vp]
+    L.dtk_multi_create.argtypes = [C.c_char_p, C.POINTER(C.c_int), u32, u64, u32, u32, C.POINTER(vp)]
+    L.dtk_multi_free.argtypes = [vp]
+    L.dtk_multi_free.restype = None
+    L.dtk_multi_type.argtypes = [vp]
+    L.dtk_multi_type.restype = C.c_char_p
+    L.dtk_multi_set_result_fields.argtypes = [vp, u32]
+    L.dtk_multi_set_chunking.argtypes = [vp, u32, u32]
+    L.dtk_multi_run.argtypes = [vp, vp, vp, u32, u32, SLICE_FN, vp]
     L.dtk_pinned_alloc.restype = vp
     L.dtk_pinned_alloc.argtypes = [sz]
     L.dtk_pinned_free.argtypes = [vp]

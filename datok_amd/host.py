@@ -504,29 +504,76 @@ class Pipeline:
         text = np.ascontiguousarray(text, dtype=np.uint8)
         doc_off = np.ascontiguousarray(doc_off, dtype=np.uint64)
         err = []
-
-        def cb(_user, first, n, handle):
-            if on_slice is None:
-                return 0
-            view = Batch.__new__(Batch)
-            try:
-                view._h = C.c_void_p(handle); view._keep = None; view.n_docs = int(n)
-                view._doc_off = (doc_off[first:first + n + 1] - doc_off[first]).astype(np.uint64)
-                view.total = int(view._doc_off[-1])
-                on_slice(int(first), int(n), view)
-                return 0
-            except Exception as e:  # noqa: BLE001  (do not unwind through the C frame)
-                err.append(e)
-                return _lib.E_STATE
-            finally:
-                # the pipeline owns the batch: the view must never free it, also not when on_slice raised and the
-                # exception's traceback keeps the view alive (a double dtk_batch_free otherwise)
-                view._h = None
-        fn = _lib.SLICE_FN(cb)
+        fn = _slice_callback(on_slice, doc_off, err)
         rc = lib().dtk_pipeline_run(self._h, tok._h, text.ctypes.data, doc_off.ctypes.data, len(doc_off) - 1, flags, fn, None)
         if err:
             raise err[0]
         check(rc, "dtk_pipeline_run")
+
+
+def _slice_callback(on_slice, doc_off, err):
+    """The C callback of dtk_pipeline_run / dtk_multi_run around a Python on_slice(first, n, batch_view)."""
+    def cb(_user, first, n, handle):
+        if on_slice is None:
+            return 0
+        view = Batch.__new__(Batch)
+        try:
+            view._h = C.c_void_p(handle); view._keep = None; view.n_docs = int(n)
+            view._doc_off = (doc_off[first:first + n + 1] - doc_off[first]).astype(np.uint64)
+            view.total = int(view._doc_off[-1])
+            on_slice(int(first), int(n), view)
+            return 0
+        except Exception as e:  # noqa: BLE001  (do not unwind through the C frame)
+            err.append(e)
+            return _lib.E_STATE
+        finally:
+            # the pipeline owns the batch: the view must never free it, also not when on_slice raised and the
+            # exception's traceback keeps the view alive (ADVICE r02: a double dtk_batch_free otherwise)
+            view._h = None
+    return _lib.SLICE_FN(cb)
+
+
+class MultiPipeline:
+    """dtk_multi: a corpus sharded over several GPUs of one node behind the C-ABI -- one worker thread, model replica
+    and pipeline per listed device, slices dealt round-robin, finished slices handed to on_slice in corpus order."""
+
+    def __init__(self, model_path, devices, slice_bytes, slice_docs, depth=3):
+        self._h = C.c_void_p()
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        check(lib().dtk_multi_create(str(model_path).encode(), devs, len(devices), int(slice_bytes), int(slice_docs),
+                                     int(depth), C.byref(self._h)), "dtk_multi_create")
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib().dtk_multi_free(h)
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def type(self):
+        return lib().dtk_multi_type(self._h).decode()
+
+    def set_result_fields(self, fields):
+        check(lib().dtk_multi_set_result_fields(self._h, int(fields)), "dtk_multi_set_result_fields")
+
+    def set_chunking(self, chunk_bytes=0xFFFFFFFF, warm_bytes=16):
+        check(lib().dtk_multi_set_chunking(self._h, int(chunk_bytes), int(warm_bytes)), "dtk_multi_set_chunking")
+
+    def run(self, text: np.ndarray, doc_off: np.ndarray, flags=0, on_slice=None):
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        doc_off = np.ascontiguousarray(doc_off, dtype=np.uint64)
+        err = []
+        fn = _slice_callback(on_slice, doc_off, err)
+        rc = lib().dtk_multi_run(self._h, text.ctypes.data, doc_off.ctypes.data, len(doc_off) - 1, flags, fn, None)
+        if err:
+            raise err[0]
+        check(rc, "dtk_multi_run")
 
 
 def foma_to_matok(foma_gz: bytes) -> bytes:

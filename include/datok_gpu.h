@@ -330,6 +330,23 @@ int dtk_pipeline_set_chunking(dtk_pipeline *p, uint32_t chunk_bytes, uint32_t wa
 int dtk_pipeline_set_result_fields(dtk_pipeline *p, uint32_t fields);
 int dtk_pipeline_run(dtk_pipeline *p, const dtk_model *m, const uint8_t *text, const uint64_t *doc_off,
                      uint32_t n_docs, uint32_t flags, dtk_slice_fn fn, void *user);
+/* ---- several GPUs of one node.  Documents are independent (matrix.go:349-381: all walk state is per call), so a corpus
+ *      shards by slices with nothing to exchange: dtk_multi keeps one worker thread per listed device, each with its
+ *      own replica of the model (loaded from model_path on that device) and its own dtk_pipeline; dtk_multi_run deals
+ *      the slices of the corpus round-robin, every device works through its share, and finished slices are handed to
+ *      `fn` on the calling thread in corpus order -- their results, if fields are selected, in the owning device's
+ *      page-locked buffers (dtk_batch_result_host inside fn).  A device may be listed more than once.  This is the
+ *      Go caller's multi-GPU entry point: fomafile.go:29-33 has no torch.distributed; the Python harness of bench.py
+ *      (one process per GPU, RCCL gather) measures the same sharding from the other side. ---- */
+typedef struct dtk_multi dtk_multi;
+int dtk_multi_create(const char *model_path, const int *devices, uint32_t n_devices, uint64_t slice_bytes,
+                     uint32_t slice_docs, uint32_t depth, dtk_multi **out);
+void dtk_multi_free(dtk_multi *mp);
+const char *dtk_multi_type(const dtk_multi *mp); /* Tokenizer.Type() */
+int dtk_multi_set_result_fields(dtk_multi *mp, uint32_t fields);
+int dtk_multi_set_chunking(dtk_multi *mp, uint32_t chunk_bytes, uint32_t warm_bytes);
+int dtk_multi_run(dtk_multi *mp, const uint8_t *text, const uint64_t *doc_off, uint32_t n_docs, uint32_t flags,
+                  dtk_slice_fn fn, void *user);
 void *dtk_pinned_alloc(size_t n); /* page-locked host memory (hipHostMalloc); NULL on failure */
 void dtk_pinned_free(void *p);
 

@@ -40,6 +40,9 @@ def test_no_cpu_fallback_without_a_device():
     assert e.value.code == _lib.E_NO_DEVICE
     with pytest.raises(_lib.DatokGpuError):
         datok_amd.Batch(1024, 4)
+    with pytest.raises(_lib.DatokGpuError) as e:
+        datok_amd.MultiPipeline(os.path.join(ROOT, "tests", "golden", "models", "simpletok.matok"), [0, 0], 1 << 16, 16)
+    assert e.value.code == _lib.E_NO_DEVICE
     assert b"no CPU path" in L.dtk_strerror(_lib.E_NO_DEVICE)
 
 

@@ -908,3 +908,43 @@ def test_pipeline_survives_a_failing_callback(gpu):
         seen = []
         p.run(tok, text, off, 0, lambda first, n, b: seen.append(b.totals()["n_tokens"]))
         assert len(seen) == 4 and all(seen)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices,prefetch", [([0, 0], 127), ([0], 0), ([0, 0, 0], 0)])
+def test_multi_device_pipeline_equals_the_oracle(gpu, oracle_models, devices, prefetch):
+    """dtk_multi: one worker thread, model replica and pipeline per listed device, slices dealt round-robin, handed to
+    the callback in corpus order (the sharding behind the C-ABI).  The one-GPU box lists its
+    device several times: the machinery (threads, hand-over, ordering, per-worker page-locked buffers) is the same."""
+    import datok_amd
+    from datok_amd import corpus
+    text, off = corpus.english_zipf_docs(2500, seed=13, max_bytes=8192)
+    om = oracle_models("tokenizer_en.matok")
+    seen, n_tok = [], [0]
+
+    def on_slice(first, n, b):
+        assert (not seen and first == 0) or first == seen[-1][0] + seen[-1][1]
+        seen.append((first, n))
+        res, tot = b.result(), b.totals()
+        assert tot["n_docs"] == n and tot["n_flagged"] == 0
+        n_tok[0] += tot["n_tokens"]
+        sub_off = (off[first:first + n + 1] - off[first]).astype(np.uint64)
+        assert_batch_equals_oracle(om, res, text[int(off[first]):int(off[first + n])], sub_off, docs=range(0, n, 6))
+    with datok_amd.MultiPipeline(os.path.join(MODELS, "tokenizer_en.matok"), devices, 1 << 19, 300, depth=3) as mp:
+        assert mp.type() == "MATOK"
+        if prefetch:
+            mp.set_result_fields(prefetch)
+        mp.run(text, off, 0, on_slice)
+        assert seen[-1][0] + seen[-1][1] == 2500 and len(seen) >= 9
+        assert n_tok[0] == int(om.count_batch(text, off, 4)[:, 0].sum())
+        # again (the workers wait for the next run), without a callback; then a callback that fails
+        mp.run(text[:int(off[700])], off[:701], 0, None)
+
+        def bad(first, n, b):
+            if first > 0:
+                raise RuntimeError("boom")
+        with pytest.raises(RuntimeError):
+            mp.run(text, off, 0, bad)
+        seen.clear(); n_tok[0] = 0
+        mp.run(text, off, 0, on_slice)      # and it still works afterwards
+        assert seen[-1][0] + seen[-1][1] == 2500
