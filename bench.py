@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--parity-docs", type=int, default=256, help="documents checked against the oracle before timing")
     ap.add_argument("--e2e-only", action="store_true", help="(internal) the PCIe-inclusive block in a process of its own")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive block (profiling runs: no child process)")
     return ap.parse_args()
 
 
@@ -279,13 +280,16 @@ def main():
     #      K = 20 steps then read 148-151 GB/s where the same 20 steps behind 200 warm-up steps read 157-158.  After
     #      these measurements the timed region finds the GPU as a running service has it.
     one = None
+    pre_steps = len(batches)  # (the parity gate's runs)
     if len(batches) > 1:
         timed_steps(batches[:1], tok, max(args.steps, 30), barrier)  # (untimed: the first launches after the idle phase)
         e1 = timed_steps(batches[:1], tok, args.steps, barrier)
         s1 = stage_times(batches[:1], tok, args.steps)
+        pre_steps += max(args.steps, 30) + args.steps + 4 * max(args.steps // 4, 2)
         one = {"value": round(total * args.steps / e1 / 1e6, 1), "ms_per_step": round(e1 / args.steps * 1e3, 4),
                "kernel_ms": round(s1["walk"], 4), "stages_ms": {k: round(v, 4) for k, v in s1.items()}}
     stage_avg = stage_times(batches, tok, args.steps)
+    pre_steps += 4 * max(args.steps // 4, 2 * len(batches))
 
     # ---- warmup
     ran = [False] * len(batches)
@@ -310,7 +314,7 @@ def main():
     #      of its own, without torch: a Go caller has none, and with torch initialised in the process the same pipeline's
     #      downloads ran at two thirds of the rate (scripts/e2e_diag2.py WITH_TORCH=1: 24 against 36.7 GB/s).
     h2d = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_e2e:
         for bb in batches:   # (their HIP streams: the runtime has four hardware queues)
             bb.close()
         import subprocess
@@ -412,15 +416,28 @@ def main():
                 traffic = tr["walk_kernel_hbm_bytes"]
         except (OSError, ValueError, KeyError):
             pass
-        workload = ("tokenizer_de.matok, %d equal-length %d B synthetic German docs per batch (BASELINE.json configs[1])"
+        mname = os.path.basename(args.model)
+        cfg_no = "configs[3]" if mname.endswith(".datok") else "configs[1]"
+        workload = (mname + ", %d equal-length %d B synthetic German docs per batch (BASELINE.json " + cfg_no + ")"
                     if world == 1 else
-                    "tokenizer_de.matok, one shard of the 10 GiB corpus per GPU: %d docs x %d B (BASELINE.json configs[4])")
+                    mname + ", one shard of the 10 GiB corpus per GPU: %d docs x %d B (BASELINE.json configs[4])")
+        info = tok.info
+        if info["kind"] == 1:
+            layout = ("dense: the double array's transitions laid out as a fused matrix at load (%d states)" % info["dense_states"]
+                      if info["dense_states"] else "pairs: the file's {base, check} pairs, two dependent loads per step")
+        else:
+            layout = "matrix: state-major %s cells" % ("fused u32" if info["entry_bytes"] == 4 else "u16")
         out = {
             "metric": "input MB/s tokenized, %s" % os.path.basename(args.model),
             "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True,
+            "warmup": args.warmup, "pre_timed_steps": pre_steps + args.warmup,
+            "pre_timed_steps_note": "untimed launches before the K timed steps: parity gate, the per-kernel measurements "
+                                    "(streams_1, stages_ms) and the W warm-up steps -- the GPU's clocks come up during them "
+                                    "(DESIGN.md section 4)",
+            "ms_per_step": round(ms_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u32 table cells, u8 symbol codes", "data": "synthetic",
             "config": {"workload": workload % (n_docs, args.doc_bytes),
+                       "table_layout": layout,
                        "docs_per_gpu": n_docs, "doc_bytes": args.doc_bytes,
                        "parallelism": "documents sharded over %d GPU(s), no data-path collective" % world,
                        "batches_in_flight": len(batches),
@@ -430,7 +447,10 @@ def main():
                          "kernel": walk_kernel_name(tok.info, bool(tot["chunk_bytes"])),
                          "achieved": round(achieved, 2),
                          "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved * 1e9 / HBM_PEAK, 6),
-                         "traffic": traffic, "algorithmic_bytes": int(b_alg),
+                         "traffic": traffic,
+                         "traffic_source": None if traffic is None else "profiles/traffic.json (rocprofv3 --pmc passes of "
+                                           "this workload, %s)" % tr.get("measured", "committed with the round's profiles"),
+                         "algorithmic_bytes": int(b_alg),
                          "kernel_ms": round(stage_avg["walk"], 4),
                          "kernel_ms_note": "average launch duration with %d batches in flight (kernels of different "
                                            "batches share the CUs); one batch alone: streams_1.kernel_ms" % len(batches),

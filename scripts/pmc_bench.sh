@@ -6,7 +6,7 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 out=gpurun_out/pmc_$tag
 mkdir -p $out
-rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $out -o pmc -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline --parity-docs 16 "$@" > $out/stdout.log 2>&1
+rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $out -o pmc -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-e2e --parity-docs 16 "$@" > $out/stdout.log 2>&1
 f=$(find $out -name "*counter_collection.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv,sys,collections

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out/$tag
 python3 bench.py > gpurun_out/$tag/bench_line.json 2> gpurun_out/$tag/bench_stderr.log || exit 1
 tail -c 600 gpurun_out/$tag/bench_line.json
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$tag/prof -o bench -- python3 bench.py --no-cpu-baseline > gpurun_out/$tag/bench_line_under_rocprof.json 2> gpurun_out/$tag/prof_stderr.log || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$tag/prof -o bench -- python3 bench.py --no-cpu-baseline --no-e2e > gpurun_out/$tag/bench_line_under_rocprof.json 2> gpurun_out/$tag/prof_stderr.log || exit 1
 f=$(find gpurun_out/$tag/prof -name "*kernel_stats.csv" | head -1)
 cp "$f" gpurun_out/$tag/kernel_stats.csv; cat gpurun_out/$tag/kernel_stats.csv
 find gpurun_out/$tag/prof -name "*kernel_trace.csv" -size +8M -delete
