@@ -517,8 +517,13 @@ static int build_datok(dtk_model *m, const std::vector<uint8_t> &raw) {
     auto step = [&](uint64_t s0, uint32_t a, uint32_t &out) -> bool {
       out = 0;
       const uint64_t idx = (uint64_t)(bc[2 * s0] & DTK_RESTBIT) + a;
-      if (idx > size) return true;         // datok.go:889: t > check(1) fails before the array is touched
-      if (idx >= L) return false;
+      if (idx >= L) return false;          // datok.go:888-889 reads array[t] before any test: an index panic
+      if (idx > size) {                    // datok.go:896: t > check(1) fails ...
+        // ... but the epsilon probe of datok.go:876 has no such bound: a hand-made file whose state "has" an epsilon
+        // arc behind check(1) remembers a slot the dense layout would not know -- the pairs are walked
+        if (a == (uint32_t)m->epsilon && (bc[2 * idx + 1] & DTK_RESTBIT) == s0) return false;
+        return true;
+      }
       if ((bc[2 * idx + 1] & DTK_RESTBIT) != s0) return true;
       uint64_t t = idx;
       if (bc[2 * idx] & DTK_FIRSTBIT) {    // separate: the representative
@@ -1075,10 +1080,12 @@ struct dtk_batch {
   enum { PB_TOK_OFF, PB_SENT_OFF, PB_TEXT_OFF, PB_RSTART, PB_REND, PB_BSTART, PB_BEND, PB_SENT, PB_TTOK, PB_TSENT,
          PB_STATUS, PB_BITS, PB_TAIL, PB_N };
   struct PinBuf { void *p = nullptr; size_t cap = 0; } pin[PB_N];
+  PinBuf h_plan;            // staging of the lane plan's tables (plan_lanes)
   uint32_t fields = DTK_R_ALL;
   hipStream_t dl_stream = nullptr;  // created with the first download, unless the caller lends one (a pipeline's slices share one:
   bool dl_own = false;              //  the runtime maps streams onto four hardware queues, and streams that share a queue serialise)
   hipEvent_t ev_ran = nullptr;      // behind the last launch of dtk_batch_run (dtk_batch_done)
+  bool ev_ran_valid = false;
   // Lent streams (dtk_batch_set_streams): the batches of a pipeline share one stream for their kernels and one for their
   // uploads -- the runtime has four hardware queues, and a pipeline of any depth then needs three (kernels, uploads,
   // downloads).  The upload's end is an event the kernels wait for.
@@ -1196,6 +1203,7 @@ extern "C" void dtk_batch_free(dtk_batch *b) {
   if (b->ev_dl) (void)hipEventDestroy(b->ev_dl);
   for (auto &pb : b->pin)
     if (pb.p) (void)hipHostFree(pb.p);
+  if (b->h_plan.p) (void)hipHostFree(b->h_plan.p);
   void *ptrs[] = {b->d_text_own, b->d_off_own, b->d_sym, b->d_rsbits, b->d_bits, b->d_acc, b->d_redo, b->d_chunk_off, b->d_blk_doc, b->d_big_docs,
                   b->d_lane_doc, b->d_lane_cnt, b->d_lane_start, b->d_lane_end, b->d_lane_plan,
                   b->d_seg_tab, b->d_seg_sum, b->d_seg_in,
@@ -1217,11 +1225,14 @@ extern "C" void *dtk_batch_stream(dtk_batch *b) { return b ? (void *)b->stream :
 
 // Everything this batch has enqueued so far has finished.  With a stream of its own: the stream; on a lent stream
 // (shared with other batches) only the batch's own last run, by its event.
+static int wait_ran(dtk_batch *b) {  // the kernels of the batch's last run (not an upload on the lent upload stream)
+  if (b->stream_own) HIP_TRY(hipStreamSynchronize(b->stream));
+  else if (b->ev_ran_valid) HIP_TRY(hipEventSynchronize(b->ev_ran));
+  return DTK_OK;
+}
 static int wait_own(dtk_batch *b) {
   if (b->up_pending) { HIP_TRY(hipEventSynchronize(b->ev_up)); }
-  if (b->stream_own || !b->ran || !b->ev_ran) HIP_TRY(hipStreamSynchronize(b->stream));
-  else HIP_TRY(hipEventSynchronize(b->ev_ran));
-  return DTK_OK;
+  return wait_ran(b);
 }
 
 extern "C" int dtk_batch_set_streams(dtk_batch *b, void *compute, void *upload) {
@@ -1309,6 +1320,20 @@ extern "C" int dtk_batch_set_warm_extend(dtk_batch *b, uint32_t max_bytes) {
 // Splits the documents into chunk lanes (host side of the speculative walk).
 static int plan_lanes(dtk_batch *b) {
   if (b->plan_valid) return DTK_OK;
+  // The tables go to the device as asynchronous copies from one page-locked staging buffer, on the stream the input
+  // was uploaded on: a pipeline of ragged slices (every slice another plan) used to wait here for the slice's upload
+  // and then for eight synchronous copies, one after the other.
+  { const int rc_ = wait_ran(b); if (rc_ != DTK_OK) return rc_; }  // (the previous run read the old tables)
+  std::vector<uint8_t> stage;
+  struct Put { void *dst; size_t at, n; };
+  std::vector<Put> puts;
+  auto put = [&](void *dst, const void *src, size_t n) {
+    if (!n) return;
+    const size_t at = (stage.size() + 15) & ~(size_t)15;
+    stage.resize(at + n);
+    memcpy(stage.data() + at, src, n);
+    puts.push_back(Put{dst, at, n});
+  };
   {
     // document of the first byte of every symbolise block (+ one entry behind the end)
     const uint64_t nblk = (b->total + DTK_SYM_BLOCK_BYTES - 1) / DTK_SYM_BLOCK_BYTES;
@@ -1320,8 +1345,7 @@ static int plan_lanes(dtk_batch *b) {
       blk[i] = d;
     }
     blk[nblk + 1] = b->n_docs - 1;
-    { const int rc_ = wait_own(b); if (rc_ != DTK_OK) return rc_; }
-    HIP_TRY(hipMemcpy(b->d_blk_doc, blk.data(), blk.size() * 4, hipMemcpyHostToDevice));
+    put(b->d_blk_doc, blk.data(), blk.size() * 4);
   }
   {
     // One lane per document pays for many tiny documents (tweets, single sentences): 64-byte documents compact five
@@ -1339,7 +1363,7 @@ static int plan_lanes(dtk_batch *b) {
     if (!e_sm && b->n_docs - big.size() < 16384u) { sm = 0; big.clear(); }
     b->small_max = sm;
     b->n_big = (uint32_t)big.size();
-    if (!big.empty()) HIP_TRY(hipMemcpy(b->d_big_docs, big.data(), big.size() * 4, hipMemcpyHostToDevice));
+    put(b->d_big_docs, big.data(), big.size() * 4);
   }
   uint32_t C = b->cfg_chunk;
   if (C == 0xFFFFFFFFu) {
@@ -1354,7 +1378,23 @@ static int plan_lanes(dtk_batch *b) {
     C = p2;
   }
   b->chunk = C;
-  if (C == 0) { b->n_lanes = 0; b->plan_valid = true; return DTK_OK; }
+  auto flush = [&]() -> int {
+    int rc_ = pin_fit(b->h_plan, stage.size());
+    if (rc_ != DTK_OK) return rc_;
+    memcpy(b->h_plan.p, stage.data(), stage.size());
+    hipStream_t us = b->up_stream ? b->up_stream : b->stream;
+    for (const Put &q : puts)
+      HIP_TRY(hipMemcpyAsync(q.dst, (const uint8_t *)b->h_plan.p + q.at, q.n, hipMemcpyHostToDevice, us));
+    if (b->up_stream) { HIP_TRY(hipEventRecord(b->ev_up, us)); b->up_pending = true; }  // (the kernels wait for this too)
+    return DTK_OK;
+  };
+  if (C == 0) {
+    b->n_lanes = 0;
+    int rc_ = flush();
+    if (rc_ != DTK_OK) return rc_;
+    b->plan_valid = true;
+    return DTK_OK;
+  }
   const uint32_t nd = b->n_docs;
   std::vector<uint32_t> chunk_off((size_t)nd + 1);
   uint64_t lanes = 0;
@@ -1413,13 +1453,13 @@ static int plan_lanes(dtk_batch *b) {
     b->seg_cap = (uint32_t)cap;
   }
   b->n_segs = ns;
-  { const int rc_ = wait_own(b); if (rc_ != DTK_OK) return rc_; }
-  HIP_TRY(hipMemcpy(b->d_seg_tab, seg_doc.data(), (size_t)ns * 4, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(b->d_seg_tab + b->seg_cap, seg_lane0.data(), (size_t)ns * 4, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(b->d_seg_tab + 2 * (size_t)b->seg_cap, seg_nl.data(), (size_t)ns * 4, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(b->d_seg_tab + 3 * (size_t)b->seg_cap, doc_seg0.data(), ((size_t)nd + 1) * 4, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(b->d_lane_doc, lane_doc.data(), lanes * 4, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(b->d_chunk_off, chunk_off.data(), ((size_t)nd + 1) * 4, hipMemcpyHostToDevice));
+  put(b->d_seg_tab, seg_doc.data(), (size_t)ns * 4);
+  put(b->d_seg_tab + b->seg_cap, seg_lane0.data(), (size_t)ns * 4);
+  put(b->d_seg_tab + 2 * (size_t)b->seg_cap, seg_nl.data(), (size_t)ns * 4);
+  put(b->d_seg_tab + 3 * (size_t)b->seg_cap, doc_seg0.data(), ((size_t)nd + 1) * 4);
+  put(b->d_lane_doc, lane_doc.data(), lanes * 4);
+  put(b->d_chunk_off, chunk_off.data(), ((size_t)nd + 1) * 4);
+  { const int rc_ = flush(); if (rc_ != DTK_OK) return rc_; }
   b->n_lanes = (uint32_t)lanes;
   b->plan_valid = true;
   return DTK_OK;
@@ -1640,6 +1680,7 @@ extern "C" int dtk_batch_run(const dtk_model *m, dtk_batch *b, uint32_t flags) {
   HIP_TRY(hipMemcpyAsync(b->h_totals, b->d_totals, DTK_TOTALS_BYTES, hipMemcpyDeviceToHost, s));
   if (!b->ev_ran) HIP_TRY(hipEventCreateWithFlags(&b->ev_ran, hipEventDisableTiming));
   HIP_TRY(hipEventRecord(b->ev_ran, s));
+  b->ev_ran_valid = true;
   b->ran = true;
   b->totals_valid = false;
   b->render_flags = 0xFFFFFFFFu;

@@ -127,7 +127,8 @@ __global__ __launch_bounds__(SYM_THREADS) void k_symbolize(const uint8_t *__rest
     // (bit = byte + document index, dtk_internal.h; neighbours overlap by a word or two), the last block the rest --
     // a few stores per lane here instead of a 10 MB clear kernel in front.
     const uint64_t ga = block_start + d_lo, gb = block_start + n_here + d_hi + 1u;
-    const uint32_t wa = (uint32_t)(ga >> 5);
+    // (block 0 from word 0: leading empty documents move d_lo, and with it `ga`, past the words of their positions)
+    const uint32_t wa = blockIdx.x == 0 ? 0u : (uint32_t)(ga >> 5);
     uint32_t wb = (uint32_t)((gb + 31u) >> 5);
     if (wb > bit_words || blockIdx.x == gridDim.x - 1) wb = bit_words;
     for (uint32_t w = wa + tid; w < wb; w += SYM_THREADS)

@@ -66,8 +66,10 @@ def datok(triple=False) -> bytes:
     return datok_from(_automaton(triple))
 
 
-def datok_from(arcs, sigma=None) -> bytes:
-    """The `.datok` image of the same kind of arc table (every arc slot "separate")."""
+def datok_from(arcs, sigma=None, size_cut=0) -> bytes:
+    """The `.datok` image of the same kind of arc table (every arc slot "separate").
+    size_cut: array[1].check -- the size every transition index is tested against (datok.go:896) -- is set that much
+    below the highest slot in use: a hand-made file in which slots behind the size still carry matching check words."""
     n, s = max(max(arcs), max(to for row in arcs.values() for to, _ in row.values())), len(sigma or SIGMA)
     size = n + 1 + (n + 1) * s
     base = [0] * (size + s + 2)
@@ -84,7 +86,7 @@ def datok_from(arcs, sigma=None) -> bytes:
             base[b + a] = to | FIRSTBIT                                     # separate: move on to the representative
             check[b + a] = t | (FIRSTBIT if nontoken else 0)
             top = max(top, b + a)
-    check[1] = top                                                          # datok.go:328-335: the array's size
+    check[1] = max(n + 1, top - size_cut)                                   # datok.go:328-335: the array's size
     pairs = [x for i in range(len(base)) for x in (base[i], check[i])]
     raw = b"DATOK" + struct.pack("<HHHHHHI", 1, EPS, UNKNOWN, IDENTITY, s, s, len(pairs)) + _sigma_bytes(sigma) + b"T"
     raw += struct.pack("<%dI" % len(pairs), *pairs)

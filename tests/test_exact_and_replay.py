@@ -26,6 +26,12 @@ def _oracle(blob):
     return O.Model(raw=gzip.decompress(blob))
 
 
+def _write(tmp_path, name, blob):
+    path = tmp_path / name
+    path.write_bytes(blob)
+    return path
+
+
 def _oracle_calls(om, doc: bytes):
     """[('T', offset, len(buf)) | ('S', arg) | ('E', arg)] in the reference's call order."""
     ev, _ = om.events(doc)
@@ -358,3 +364,36 @@ def test_converted_double_array_on_the_device(tmp_path):
         assert assert_batch_equals_oracle(om, res, text, off, 0) == len(off) - 1
         for k in ("tok_off", "sent_off", "tok_rstart", "tok_rend", "tok_bstart", "tok_bend", "sent"):
             assert np.array_equal(getattr(res, k), getattr(resm, k)), k
+
+
+@pytest.mark.gpu
+def test_double_array_with_slots_behind_its_size(tmp_path):
+    """ADVICE r02.  datok.go:876 probes a state's epsilon slot without the size bound that datok.go:896 puts on every
+    transition: in a hand-made (or truncated) file a state can "have" an epsilon arc -- a remembered slot to backtrack
+    to -- that no transition can take.  ToDoubleArray never writes such a file and the reference holds none (parity
+    unpinned, the oracle is the restatement); the dense layout does not apply to one (the pairs are walked) and the
+    result must equal the oracle's either way."""
+    import datok_amd
+    from datok_amd import corpus
+    rng = np.random.default_rng(77)
+    docs = craft.documents(rng, 200) + craft.random_documents(rng, 100)
+    text, off = corpus.concat_docs(docs)
+    fell_back = compared = 0
+    for arcs in (craft._automaton(False), craft.random_automaton(np.random.default_rng(14))):
+        whole = datok_amd.load_tokenizer_file(str(_write(tmp_path, "whole.datok", craft.datok_from(arcs))))
+        for cut in (1, 4, 9, 14, 20):
+            blob = craft.datok_from(arcs, size_cut=cut)
+            tok, om = datok_amd.load_tokenizer_file(str(_write(tmp_path, "cut%d.datok" % cut, blob))), _oracle(blob)
+            assert tok is not None
+            if whole.info["dense_states"] and not tok.info["dense_states"]:
+                fell_back += 1
+            for chunk in (0, 16):
+                with datok_amd.Batch(len(text), len(docs)) as b:
+                    b.set_chunking(chunk, 8, extend=0)
+                    b.set_input(text, off)
+                    b.run(tok, 0)
+                    # (ST_BAD_MODEL: at the end of a document such a state makes the reference take an epsilon step that
+                    #  fails with nothing buffered -- it then emits a rune from behind its buffer's fill mark,
+                    #  datok.go:942-951; the library flags the document instead of inventing that rune)
+                    compared += assert_batch_equals_oracle(om, b.result(), text, off, 0, skip_status=datok_amd.ST_BAD_MODEL)
+    assert fell_back > 0 and compared > 1000   # (some cut put an epsilon slot behind the size)

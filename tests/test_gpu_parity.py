@@ -4,6 +4,8 @@ import io
 import os
 import sys
 
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -12,6 +14,7 @@ from goldens import failed_checks, golden_strings, load_cases, model_file
 from parity import assert_batch_equals_oracle, oracle_doc
 
 pytestmark = pytest.mark.gpu
+C_byref = ctypes.byref
 
 TOKENS, SENTENCES, TOKEN_POS, SENTENCE_POS, NEWLINE_AFTER_EOT = 1, 2, 4, 8, 16
 SIMPLE = TOKENS | SENTENCES
@@ -948,3 +951,26 @@ def test_multi_device_pipeline_equals_the_oracle(gpu, oracle_models, devices, pr
         seen.clear(); n_tok[0] = 0
         mp.run(text, off, 0, on_slice)      # and it still works afterwards
         assert seen[-1][0] + seen[-1][1] == 2500
+
+
+@pytest.mark.gpu
+def test_leading_empty_documents_on_a_reused_batch(gpu, oracle_models):
+    """k_symbolize's blocks clear the event bitmaps; block 0 must start at word 0 -- with 32 or more leading
+    empty documents its first document is not document 0, and the words of the empty documents' positions kept the
+    previous run's bits (the result stayed right only because those documents then went through the exact pass)."""
+    import datok_amd
+    from datok_amd import corpus
+    tok, om = gpu("tokenizer_de.matok"), oracle_models("tokenizer_de.matok")
+    t1, o1 = corpus.german_docs(300, 600, seed=31)
+    body, ob = corpus.german_docs(200, 600, seed=32)
+    t2 = body
+    o2 = np.concatenate([np.zeros(100, np.uint64), ob])      # 100 empty documents in front
+    with datok_amd.Batch(len(t1) + 1024, 400) as b:
+        b.set_input(t1, o1); b.run(tok, 0); b.totals()           # leaves bits all over the first words
+        b.set_input(t2, o2); b.run(tok, 0)
+        res = b.result()
+        v = datok_amd._lib.ResultView()
+        datok_amd.lib().dtk_batch_result_device(b._h, C_byref(v))
+        assert v.n_exact == 0                                     # nobody needed the exact pass
+        assert_batch_equals_oracle(om, res, t2, o2, docs=list(range(0, 100, 9)) + list(range(100, 300, 7)), allow_status=2)
+        assert all(int(res.tok_off[d + 1]) == int(res.tok_off[d]) for d in range(100))
