@@ -396,4 +396,6 @@ def test_double_array_with_slots_behind_its_size(tmp_path):
                     #  fails with nothing buffered -- it then emits a rune from behind its buffer's fill mark,
                     #  datok.go:942-951; the library flags the document instead of inventing that rune)
                     compared += assert_batch_equals_oracle(om, b.result(), text, off, 0, skip_status=datok_amd.ST_BAD_MODEL)
-    assert fell_back > 0 and compared > 1000   # (some cut put an epsilon slot behind the size)
+    assert compared > 1000
+    if not any(os.environ.get(k) for k in ("DATOK_NO_DENSE", "DATOK_NO_FUSED", "DATOK_FORCE_WIDE")):
+        assert fell_back > 0   # (some cut put an epsilon slot behind the size: no dense layout for that file)
