@@ -39,11 +39,31 @@ __global__ __launch_bounds__(64) void k_rate(unsigned long long *out, unsigned *
         asm volatile("v_add_u32 %0, %0, %1\nv_add_u32 %0, %0, %1\nv_add_u32 %0, %0, %1\nv_add_u32 %0, %0, %1\n"
                      "v_add_u32 %0, %0, %1\nv_add_u32 %0, %0, %1\nv_add_u32 %0, %0, %1\nv_add_u32 %0, %0, %1\n" : "+v"(a0) : "v"(k));
       }
-      if (KIND == 6) {  // vector compare into an SGPR pair, scalar and, select: the VALU -> SALU -> VALU hand-over
-        unsigned long long m;
-        asm volatile("v_cmp_lt_u32 %1, %0, %3\ns_and_b64 %1, %1, exec\nv_cndmask_b32 %0, %0, %3, %1\n"
-                     "v_cmp_lt_u32 %1, %2, %3\ns_and_b64 %1, %1, exec\nv_cndmask_b32 %2, %2, %3, %1\n"
-                     : "+v"(a0), "=s"(m), "+v"(a1) : "v"(k));
+      if (KIND == 6) {  // vector compare -> scalar and -> select: the VALU -> SALU -> VALU hand-over (6 instructions)
+        asm volatile("v_cmp_lt_u32 vcc, %0, %2\ns_and_b64 vcc, vcc, exec\nv_cndmask_b32 %0, %0, %2, vcc\n"
+                     "v_cmp_lt_u32 vcc, %1, %2\ns_and_b64 vcc, vcc, exec\nv_cndmask_b32 %1, %1, %2, vcc\n"
+                     : "+v"(a0), "+v"(a1) : "v"(k) : "vcc", "scc");
+      }
+      if (KIND == 7) {  // the same without the scalar instruction (4 instructions)
+        asm volatile("v_cmp_lt_u32 vcc, %0, %2\nv_cndmask_b32 %0, %0, %2, vcc\n"
+                     "v_cmp_lt_u32 vcc, %1, %2\nv_cndmask_b32 %1, %1, %2, vcc\n"
+                     : "+v"(a0), "+v"(a1) : "v"(k) : "vcc");
+      }
+      if (KIND == 8) {  // scalar chain: 8 dependent s_and_b64 / s_or_b64
+        asm volatile("s_and_b64 vcc, vcc, exec\ns_or_b64 vcc, vcc, exec\ns_and_b64 vcc, vcc, exec\ns_or_b64 vcc, vcc, exec\n"
+                     "s_and_b64 vcc, vcc, exec\ns_or_b64 vcc, vcc, exec\ns_and_b64 vcc, vcc, exec\ns_or_b64 vcc, vcc, exec\n" ::: "vcc", "scc");
+      }
+      if (KIND == 9) {  // compare into a scalar pair, two scalar ops on it, select (the walk's predicate pattern; 8 instructions)
+        asm volatile("v_cmp_lt_u32 s[20:21], %0, %2\nv_cmp_gt_u32 s[22:23], %1, %2\ns_and_b64 s[20:21], s[20:21], s[22:23]\n"
+                     "v_cndmask_b32 %0, %0, %2, s[20:21]\n"
+                     "v_cmp_lt_u32 s[24:25], %1, %2\nv_cmp_gt_u32 s[26:27], %0, %2\ns_or_b64 s[24:25], s[24:25], s[26:27]\n"
+                     "v_cndmask_b32 %1, %1, %2, s[24:25]\n"
+                     : "+v"(a0), "+v"(a1) : "v"(k) : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "scc");
+      }
+      if (KIND == 10) {  // a taken uniform branch per 4 vector instructions
+        asm volatile("v_add_u32 %0, %0, %2\nv_add_u32 %1, %1, %2\ns_cbranch_scc1 1f\n1:\nv_add_u32 %0, %0, %2\nv_add_u32 %1, %1, %2\n"
+                     "s_cmp_eq_u32 s20, s20\ns_cbranch_scc1 2f\ns_nop 0\n2:\n"
+                     : "+v"(a0), "+v"(a1) : "v"(k) : "s20", "scc");
       }
     }
   }
@@ -58,12 +78,12 @@ static void run(const char *name, int per_rep) {
   unsigned *sink;
   hipMalloc(&d, 8 * 8192 * 8);
   hipMalloc(&sink, 64);
-  printf("%-34s", name);
+  printf("%-34s", name); fflush(stdout);
   for (int w : {1, 2, 3, 4, 6, 8}) {
     const int blocks = 256 * 4 * w;
     hipLaunchKernelGGL(k_rate<KIND>, dim3(blocks), dim3(64), 0, 0, d, sink, 3u);
     hipLaunchKernelGGL(k_rate<KIND>, dim3(blocks), dim3(64), 0, 0, d, sink, 3u);
-    hipDeviceSynchronize();
+    if (hipDeviceSynchronize() != hipSuccess) { printf(" launch failed: %s", hipGetErrorString(hipGetLastError())); break; }
     std::vector<unsigned long long> h(blocks);
     hipMemcpy(h.data(), d, blocks * 8, hipMemcpyDeviceToHost);
     std::sort(h.begin(), h.end());
@@ -83,6 +103,10 @@ int main() {
   run<3>("v_cmp + v_cndmask (vcc)", 64);
   run<4>("v_fma_f32", 64);
   run<5>("v_add_u32 dependent chain", 64);
-  run<6>("v_cmp -> s_and -> v_cndmask", 48);
+  run<6>("v_cmp -> s_and -> v_cndmask (vcc)", 48);
+  run<7>("v_cmp -> v_cndmask (vcc), dependent", 32);
+  run<8>("s_and/s_or dependent chain", 64);
+  run<9>("2 v_cmp_e64, s_op, v_cndmask", 64);
+  run<10>("4 v_add + 2 taken branches + s_cmp", 56);
   return 0;
 }
