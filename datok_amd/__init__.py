@@ -22,6 +22,6 @@ HIP kernels behind the C-ABI of libdatok_gpu.so (include/datok_gpu.h):
 """
 from ._lib import (DatokGpuError, ST_BAD_MODEL, ST_BAD_OFFSET, ST_EMPTY_TEXT, ST_IRREGULAR, ST_STEP_LIMIT,  # noqa: F401
                    ST_WINDOW_OVERFLOW, build, lib)
-from .host import (NEWLINE_AFTER_EOT, SENTENCE_POS, SENTENCES, SIMPLE, TOKEN_POS, TOKENS, Batch,  # noqa: F401
+from .host import (NEWLINE_AFTER_EOT, NO_BYTE_OFFSETS, NO_RUNE_OFFSETS, OFFSETS_ONLY, SENTENCE_POS, SENTENCES, SIMPLE, TOKEN_POS, TOKENS, Batch,  # noqa: F401
                    BatchResult, MultiPipeline, PinnedBuffer, Pipeline, TokenWriter, Tokenizer, foma_to_datok, foma_to_matok, load_foma_file,
                    load_tokenizer_file, new_token_writer, replay)

@@ -278,10 +278,8 @@ __device__ __forceinline__ void compact_unit(const DtkCompactArgs &A, uint32_t s
 
       {
         if (isEnd && tok_base + k < tok_lim) {
-          A.tok_bstart[tok_base + k] = startP;
-          A.tok_bend[tok_base + k] = P;
-          A.tok_rstart[tok_base + k] = rstart;
-          A.tok_rend[tok_base + k] = rend;
+          if (A.tok_bstart) { A.tok_bstart[tok_base + k] = startP; A.tok_bend[tok_base + k] = P; }
+          if (A.tok_rstart) { A.tok_rstart[tok_base + k] = rstart; A.tok_rend[tok_base + k] = rend; }
           if (A.tok_sbefore) A.tok_sbefore[tok_base + k] = sBeforeEnd;  // SentenceEnd calls before this Token call
         }
         uint64_t si = sent_base + cNSent + excl;
@@ -456,8 +454,8 @@ __device__ __forceinline__ void compact_unit(const DtkCompactArgs &A, uint32_t s
         }
         if (k >= tok_lim) status |= ST_INTERNAL;
         else if (far || li >= CT_CAP) {
-          A.tok_bstart[k] = sp; A.tok_bend[k] = P;
-          A.tok_rstart[k] = (int32_t)(sR - base); A.tok_rend[k] = (int32_t)(R - base);
+          if (A.tok_bstart) { A.tok_bstart[k] = sp; A.tok_bend[k] = P; }
+          if (A.tok_rstart) { A.tok_rstart[k] = (int32_t)(sR - base); A.tok_rend[k] = (int32_t)(R - base); }
           if (A.tok_sbefore) A.tok_sbefore[k] = cNSev + sbef;
         }
         if (sfm & (1u << b)) {  // token_writer.go:76-79
@@ -487,8 +485,9 @@ __device__ __forceinline__ void compact_unit(const DtkCompactArgs &A, uint32_t s
           const uint2 v = s_tok[i];
           const uint64_t k = tok_base + cTE + i;
           if ((v.x & 0xFFFFu) != 0xFFFFu) {
-            A.tok_bstart[k] = (v.x & 0xFFFFu) + pb; A.tok_bend[k] = (v.x >> 16) + pb;
-            A.tok_rstart[k] = (int32_t)((v.y & 0xFFFFu) + rb); A.tok_rend[k] = (int32_t)((v.y >> 16) + rb);
+            // (a caller that reads one kind of offsets does not pay for the stores of the other: DTK_NO_*_OFFSETS)
+            if (A.tok_bstart) { A.tok_bstart[k] = (v.x & 0xFFFFu) + pb; A.tok_bend[k] = (v.x >> 16) + pb; }
+            if (A.tok_rstart) { A.tok_rstart[k] = (int32_t)((v.y & 0xFFFFu) + rb); A.tok_rend[k] = (int32_t)((v.y >> 16) + rb); }
             if (A.tok_sbefore) A.tok_sbefore[k] = cNSev + s_sb[i];
           }
         }
@@ -736,8 +735,8 @@ __global__ __launch_bounds__(256) void k_compact_small(DtkCompactArgs A, uint32_
         posC += (int32_t)(R - Rcs);
         last_rend = posC;
         if (n_tok < tok_n) {
-          A.tok_bstart[tok_base + n_tok] = cs; A.tok_bend[tok_base + n_tok] = p;
-          A.tok_rstart[tok_base + n_tok] = rs; A.tok_rend[tok_base + n_tok] = posC;
+          if (A.tok_bstart) { A.tok_bstart[tok_base + n_tok] = cs; A.tok_bend[tok_base + n_tok] = p; }
+          if (A.tok_rstart) { A.tok_rstart[tok_base + n_tok] = rs; A.tok_rend[tok_base + n_tok] = posC; }
           if (A.tok_sbefore) A.tok_sbefore[tok_base + n_tok] = n_sev;
         } else st |= ST_INTERNAL;
         n_tok++;

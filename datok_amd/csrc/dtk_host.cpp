@@ -1508,10 +1508,11 @@ static uint32_t cmp_mask_of(const dtk_model *m) {
 // which: 1 the documents without an EOT call, 2 those with one, 3 both (dtk_launch_compact)
 static int launch_compact2(dtk_batch *b, int which) {
   DtkCompactArgs a = b->last_args;
-  a.tok_rstart = b->d_rstart; a.tok_rend = b->d_rend;
-  a.tok_bstart = b->d_bstart; a.tok_bend = b->d_bend;
+  const bool no_rune = (b->last_flags & DTK_NO_RUNE_OFFSETS) != 0, no_byte = (b->last_flags & DTK_NO_BYTE_OFFSETS) != 0;
+  a.tok_rstart = no_rune ? nullptr : b->d_rstart; a.tok_rend = no_rune ? nullptr : b->d_rend;
+  a.tok_bstart = no_byte ? nullptr : b->d_bstart; a.tok_bend = no_byte ? nullptr : b->d_bend;
   a.sent = b->d_sent; a.text_tok_end = b->d_ttok; a.text_sent_end = b->d_tsent;
-  const bool ro = (b->last_flags & DTK_OFFSETS_ONLY) != 0;  // no renderer bookkeeping
+  const bool ro = (b->last_flags & (DTK_OFFSETS_ONLY | DTK_NO_RUNE_OFFSETS | DTK_NO_BYTE_OFFSETS)) != 0;  // no renderer bookkeeping
   a.tok_sbefore = ro ? nullptr : b->d_sbefore; a.text_s_end = ro ? nullptr : b->d_ts_end;
   a.doc_ns = ro ? nullptr : b->d_doc_ns;
   a.tok_cap = b->tok_cap; a.sent_cap = b->sent_cap; a.text_cap = b->text_cap;
@@ -1748,9 +1749,11 @@ static int run_exact(dtk_batch *b) {
   X.n_calls = b->d_exact_cnt; X.call_off = b->d_exact_off; X.status = b->d_status;
   X.flags = b->last_flags & DTK_NEWLINE_AFTER_EOT; X.step_factor = walk_args(b).step_factor;
   X.tok_off = b->d_tok_off; X.sent_off = b->d_sent_off; X.text_off = b->d_text_off;
-  X.tok_rstart = b->d_rstart; X.tok_rend = b->d_rend; X.tok_bstart = b->d_bstart; X.tok_bend = b->d_bend;
+  const bool no_rune = (b->last_flags & DTK_NO_RUNE_OFFSETS) != 0, no_byte = (b->last_flags & DTK_NO_BYTE_OFFSETS) != 0;
+  X.tok_rstart = no_rune ? nullptr : b->d_rstart; X.tok_rend = no_rune ? nullptr : b->d_rend;
+  X.tok_bstart = no_byte ? nullptr : b->d_bstart; X.tok_bend = no_byte ? nullptr : b->d_bend;
   X.sent = b->d_sent; X.text_tok_end = b->d_ttok; X.text_sent_end = b->d_tsent;
-  const bool ro = (b->last_flags & DTK_OFFSETS_ONLY) != 0;
+  const bool ro = (b->last_flags & (DTK_OFFSETS_ONLY | DTK_NO_RUNE_OFFSETS | DTK_NO_BYTE_OFFSETS)) != 0;
   X.tok_sbefore = ro ? nullptr : b->d_sbefore; X.text_s_end = ro ? nullptr : b->d_ts_end;
   X.doc_ns = ro ? nullptr : b->d_doc_ns;
   X.pass = 0;
@@ -1926,8 +1929,9 @@ extern "C" int dtk_batch_result_device(dtk_batch *b, dtk_result_view *o) {
   int rc = finish(b);
   if (rc != DTK_OK) return rc;
   o->tok_off = b->d_tok_off; o->sent_off = b->d_sent_off; o->text_off = b->d_text_off;
-  o->tok_rstart = b->d_rstart; o->tok_rend = b->d_rend;
-  o->tok_bstart = b->d_bstart; o->tok_bend = b->d_bend;
+  const bool no_rune = (b->last_flags & DTK_NO_RUNE_OFFSETS) != 0, no_byte = (b->last_flags & DTK_NO_BYTE_OFFSETS) != 0;
+  o->tok_rstart = no_rune ? nullptr : b->d_rstart; o->tok_rend = no_rune ? nullptr : b->d_rend;
+  o->tok_bstart = no_byte ? nullptr : b->d_bstart; o->tok_bend = no_byte ? nullptr : b->d_bend;
   o->sent = b->d_sent; o->text_tok_end = b->d_ttok; o->text_sent_end = b->d_tsent;
   o->status = b->d_status; o->ev_bits = b->d_bits; o->ev_words = b->bit_words; o->doc_tail = b->d_doc_tail;
   o->n_exact = (uint32_t)b->h_exact_ids.size();
@@ -1944,7 +1948,9 @@ extern "C" int dtk_batch_set_result_fields(dtk_batch *b, uint32_t fields) {
 // DTK_R_EAGER: the selected arrays leave for the host inside the run, by a kernel behind the compaction that reads
 // the sizes where they are -- on the device (k_to_host).  Page-locked buffers sized like the device arrays.
 static int launch_to_host(dtk_batch *b) {
-  const uint32_t f = b->fields;
+  uint32_t f = b->fields;
+  if (b->last_flags & DTK_NO_RUNE_OFFSETS) f &= ~(uint32_t)DTK_R_TOK_RUNE;
+  if (b->last_flags & DTK_NO_BYTE_OFFSETS) f &= ~(uint32_t)DTK_R_TOK_BYTE;
   DtkToHostArgs a{};
   const uint64_t nd = b->n_docs;
   auto add = [&](int which, const void *src, uint64_t bytes_or_elem, int count_from, uint64_t cap) -> int {
@@ -2016,7 +2022,9 @@ extern "C" int dtk_batch_download_begin(dtk_batch *b) {
   int rc = finish(b);
   if (rc != DTK_OK) return rc;
 
-  const uint32_t sel = b->fields & DTK_R_ALL;
+  uint32_t sel = b->fields & DTK_R_ALL;
+  if (b->last_flags & DTK_NO_RUNE_OFFSETS) sel &= ~(uint32_t)DTK_R_TOK_RUNE;  // (not written by this run)
+  if (b->last_flags & DTK_NO_BYTE_OFFSETS) sel &= ~(uint32_t)DTK_R_TOK_BYTE;
   if (b->dl_begun && (b->dl_fields & sel) == sel) return DTK_OK;
   const uint32_t want = sel & ~(b->dl_begun ? b->dl_fields : 0u);
   if (!dtk_batch_download_stream(b)) return hip_fail(hipGetLastError(), "download stream");
@@ -2092,7 +2100,7 @@ static int render(dtk_batch *b, uint32_t bits) {
   int rc = finish(b);
   if (rc != DTK_OK) return rc;
   if (bits & ~31u) return DTK_E_ARG;
-  if (b->last_flags & DTK_OFFSETS_ONLY) return DTK_E_STATE;  // the run skipped the renderer's bookkeeping
+  if (b->last_flags & (DTK_OFFSETS_ONLY | DTK_NO_RUNE_OFFSETS | DTK_NO_BYTE_OFFSETS)) return DTK_E_STATE;  // the run skipped what the renderer reads
   // the positions were computed under the run's NEWLINE_AFTER_EOT rule (token_writer.go:66-68)
   if ((bits ^ b->last_flags) & DTK_NEWLINE_AFTER_EOT) return DTK_E_ARG;
   bits &= 15u;

@@ -80,8 +80,8 @@ struct ExactSink {
     last_rend = posC;
     if (write) {
       if (n_tok < tok_n) {
-        rstart[n_tok] = rs; rend[n_tok] = posC;
-        bstart[n_tok] = tp < p ? tp : p; bend[n_tok] = p;  // an empty surface: the empty range at the end of the buffer
+        if (rstart) { rstart[n_tok] = rs; rend[n_tok] = posC; }
+        if (bstart) { bstart[n_tok] = tp < p ? tp : p; bend[n_tok] = p; }  // an empty surface: the empty range at the end of the buffer
         if (sbefore) sbefore[n_tok] = n_sev;
       } else st |= ST_INTERNAL;
     }
@@ -121,8 +121,8 @@ __global__ __launch_bounds__(WAVE) void k_exact_doc(TRANS tr, DtkExactArgs X, ui
   sink.nl_rule = (X.flags & 16u) != 0; sink.write = X.pass != 0;
   sink.log = X.pass ? X.calls + X.call_off[i] : nullptr;
   const uint64_t t0 = X.tok_off[d], s0 = X.sent_off[d], x0 = X.text_off[d];
-  sink.rstart = X.tok_rstart + t0; sink.rend = X.tok_rend + t0;
-  sink.bstart = X.tok_bstart + t0; sink.bend = X.tok_bend + t0;
+  sink.rstart = X.tok_rstart ? X.tok_rstart + t0 : nullptr; sink.rend = X.tok_rend ? X.tok_rend + t0 : nullptr;
+  sink.bstart = X.tok_bstart ? X.tok_bstart + t0 : nullptr; sink.bend = X.tok_bend ? X.tok_bend + t0 : nullptr;
   sink.sbefore = X.tok_sbefore ? X.tok_sbefore + t0 : nullptr;
   sink.sent = X.sent + s0;
   sink.ttok = X.text_tok_end + x0; sink.tsent = X.text_sent_end + x0;

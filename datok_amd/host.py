@@ -11,6 +11,8 @@ from ._lib import ModelInfo, RenderView, ResultView, Totals, check, lib
 # token_writer.go:17-25
 TOKENS, SENTENCES, TOKEN_POS, SENTENCE_POS, NEWLINE_AFTER_EOT = 1, 2, 4, 8, 16
 SIMPLE = TOKENS | SENTENCES
+# dtk_batch_run only (datok_gpu.h): no renderer bookkeeping / only one kind of token offsets
+OFFSETS_ONLY, NO_BYTE_OFFSETS, NO_RUNE_OFFSETS = 256, 512, 1024
 OFFSETS_ONLY = 256   # Batch.run only: skip the device renderer's bookkeeping
 
 # calls at one cursor position, in the order they fire (flag byte of event_bytes(); datok_gpu.h DTK_EVB_* / DTK_TAIL_*)
@@ -302,6 +304,7 @@ class BatchResult:
         return event_bytes(self.ev_bits, self.doc_off[d], d, n, self.doc_tail[d])
 
     def doc(self, d):
+        """The rows of document d (arrays the run did not write or the caller did not select are empty)."""
         a, b = int(self.tok_off[d]), int(self.tok_off[d + 1])
         s0, s1 = int(self.sent_off[d]), int(self.sent_off[d + 1])
         t0, t1 = int(self.text_off[d]), int(self.text_off[d + 1])

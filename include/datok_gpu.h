@@ -50,7 +50,13 @@ enum {
   DTK_SIMPLE = 3,
   /* dtk_batch_run only (not a reference bit): the caller wants the offset arrays only; the
    * per-token bookkeeping of dtk_batch_render_* is not written (a render then returns DTK_E_STATE) */
-  DTK_OFFSETS_ONLY = 256
+  DTK_OFFSETS_ONLY = 256,
+  /* dtk_batch_run only, each implies DTK_OFFSETS_ONLY: a caller that reads one kind of token offsets does not pay for
+   * the other (the compaction otherwise writes four 32-bit words per token where the north star's arrays have two;
+   * tok_rstart / tok_rend resp. tok_bstart / tok_bend then come back NULL).  The closure replay and the device
+   * renderer need the byte offsets. */
+  DTK_NO_BYTE_OFFSETS = 512,
+  DTK_NO_RUNE_OFFSETS = 1024
 };
 
 /* ---- per-document status bits: inputs on which the reference panics or

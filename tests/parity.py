@@ -10,7 +10,7 @@ def oracle_doc(omodel, doc: bytes, flags=0):
 
 
 def assert_batch_equals_oracle(omodel, res, text: np.ndarray, doc_off: np.ndarray, flags=0,
-                               docs=None, allow_status=0, skip_status=0):
+                               docs=None, allow_status=0, skip_status=0, fields=FIELDS):
     """res: datok_amd.BatchResult. docs: iterable of doc ids to check (default all).
 
     Documents whose oracle status is non-zero are out of contract (the reference
@@ -34,7 +34,7 @@ def assert_batch_equals_oracle(omodel, res, text: np.ndarray, doc_off: np.ndarra
         assert (got["status"] & ~allow_status) == (exp["status"] & ~allow_status), (d, got["status"], exp["status"], raw[a:b][:80])
         if exp["status"]:
             continue
-        for f in FIELDS:
+        for f in fields:
             g, e = np.asarray(got[f]).astype(np.int64), np.asarray(exp[f]).astype(np.int64)
             if g.shape != e.shape or not np.array_equal(g, e):
                 k = 0

@@ -974,3 +974,36 @@ def test_leading_empty_documents_on_a_reused_batch(gpu, oracle_models):
         assert v.n_exact == 0                                     # nobody needed the exact pass
         assert_batch_equals_oracle(om, res, t2, o2, docs=list(range(0, 100, 9)) + list(range(100, 300, 7)), allow_status=2)
         assert all(int(res.tok_off[d + 1]) == int(res.tok_off[d]) for d in range(100))
+
+
+@pytest.mark.gpu
+def test_one_kind_of_token_offsets(gpu, oracle_models):
+    """DTK_NO_BYTE_OFFSETS / DTK_NO_RUNE_OFFSETS: the compaction writes two of its four offset arrays; the others come
+    back empty, everything else is unchanged.  EOT texts, tiny documents (the lane-per-document kernel) and the exact
+    pass's rows included."""
+    import datok_amd
+    from datok_amd import corpus
+    tok, om = gpu("tokenizer_de.matok"), oracle_models("tokenizer_de.matok")
+    t1, o1 = corpus.german_docs(500, 700, seed=41)
+    docs = [t1[int(o1[d]):int(o1[d + 1])].tobytes() for d in range(500)]
+    docs[7] = "Erste.\n\n\x04\nNächst.\x04".encode()            # matrix_test.go:1308-1310
+    docs[8] = b"This.\n\x04And.\n\x04\n"                          # token_writer_test.go:50
+    docs += [b"Hallo Welt. " * 3] * 2600                            # enough tiny documents for k_compact_small
+    text, off = corpus.concat_docs(docs)
+    rune = ("tok_rstart", "tok_rend", "sent", "text_tok_end", "text_sent_end")
+    byte = ("tok_bstart", "tok_bend", "sent", "text_tok_end", "text_sent_end")
+    for flags, fields, empty in ((datok_amd.NO_BYTE_OFFSETS, rune, "tok_bstart"), (datok_amd.NO_RUNE_OFFSETS, byte, "tok_rstart"),
+                                 (datok_amd.NO_BYTE_OFFSETS | NEWLINE_AFTER_EOT, rune, "tok_bend")):
+        for chunk in (None, 0, 64):
+            with datok_amd.Batch(len(text), len(docs)) as b:
+                if chunk is not None:
+                    b.set_chunking(chunk, 16)
+                b.set_input(text, off)
+                b.run(tok, flags)
+                res = b.result()
+                assert len(getattr(res, empty)) == 0
+                n = assert_batch_equals_oracle(om, res, text, off, flags & NEWLINE_AFTER_EOT, docs=range(0, len(docs), 7),
+                                               fields=fields)
+                assert n > 400
+                with pytest.raises(datok_amd.DatokGpuError):
+                    b.render(3)      # (the renderer needs both kinds)
