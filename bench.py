@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--doc-bytes", type=int, default=4096)
     ap.add_argument("--model", default=MODEL)
     ap.add_argument("--chunk", type=int, default=-1, help="-1 automatic, 0 one lane per document, else bytes")
-    ap.add_argument("--warm", type=int, default=16)
+    ap.add_argument("--warm", type=int, default=8)
     ap.add_argument("--streams", type=int, default=0,
                     help="batches in flight (default 3 at N = 1, 1 at N > 1): consecutive steps alternate between "
                          "this many dtk_batch objects, each with its own input (seeds 2, 3, ...), HIP stream and buffers")

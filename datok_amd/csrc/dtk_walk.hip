@@ -320,8 +320,11 @@ __global__ __launch_bounds__(WAVE) void k_spec_start(TRANS tr, DtkWalkArgs A, Dt
 // with a record walks; what lanes behind a broken chain stored is cleared by the repair round.
 extern __shared__ uint32_t s_dyn_bits[];  // the wave's event bitmaps (3 kinds x S.lds_words), if any
 
+#ifndef DTK_WALK_OCC
+#define DTK_WALK_OCC 7  // the lean loop in 72 VGPRs (the allocator finds them without another spill): 7 waves per SIMD where LDS allows (three batches in flight: walk -5 %)
+#endif
 template <typename TRANS, bool IS_MATRIX>
-__global__ __launch_bounds__(WAVE) void k_spec_both(TRANS tr, DtkWalkArgs A, DtkSpecArgs S,
+__global__ __launch_bounds__(WAVE, TRANS::LEAN ? DTK_WALK_OCC : 1) void k_spec_both(TRANS tr, DtkWalkArgs A, DtkSpecArgs S,
                                                     uint32_t epsilon, uint32_t unknown,
                                                     uint32_t identity) {
   DTK_WINDOWS(TRANS, A.sym)

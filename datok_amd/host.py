@@ -369,7 +369,7 @@ class Batch:
 
     AUTO_CHUNK = 0xFFFFFFFF
 
-    def set_chunking(self, chunk_bytes=AUTO_CHUNK, warm_bytes=16, extend=None):
+    def set_chunking(self, chunk_bytes=AUTO_CHUNK, warm_bytes=8, extend=None):
         """0: one lane per document; otherwise speculative chunk lanes (exact either way).
         extend: how far the warm-up start may move back to the previous blank (None: library default,
         0: fixed distance only -- what tests use to force mispredictions)."""
@@ -496,7 +496,7 @@ class Pipeline:
     def __exit__(self, *a):
         self.close()
 
-    def set_chunking(self, chunk_bytes=0xFFFFFFFF, warm_bytes=16):
+    def set_chunking(self, chunk_bytes=0xFFFFFFFF, warm_bytes=8):
         check(lib().dtk_pipeline_set_chunking(self._h, int(chunk_bytes), int(warm_bytes)), "dtk_pipeline_set_chunking")
 
     def set_result_fields(self, fields):
@@ -565,7 +565,7 @@ class MultiPipeline:
     def set_result_fields(self, fields):
         check(lib().dtk_multi_set_result_fields(self._h, int(fields)), "dtk_multi_set_result_fields")
 
-    def set_chunking(self, chunk_bytes=0xFFFFFFFF, warm_bytes=16):
+    def set_chunking(self, chunk_bytes=0xFFFFFFFF, warm_bytes=8):
         check(lib().dtk_multi_set_chunking(self._h, int(chunk_bytes), int(warm_bytes)), "dtk_multi_set_chunking")
 
     def run(self, text: np.ndarray, doc_off: np.ndarray, flags=0, on_slice=None):

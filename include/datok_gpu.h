@@ -152,7 +152,7 @@ int dtk_batch_set_input_device(dtk_batch *b, const void *d_text, const void *d_d
  * speculative start found warm_bytes earlier, and a check pass proves that each
  * lane arrived exactly where its successor started (mismatches are repaired, the
  * result is always exact).  0xFFFFFFFF (the default) picks the chunk size from
- * the batch size.  warm_bytes defaults to 16 (the start then moves back to the previous blank, see below). */
+ * the batch size.  warm_bytes defaults to 8 (the start then moves back to the previous blank, see below). */
 int dtk_batch_set_chunking(dtk_batch *b, uint32_t chunk_bytes, uint32_t warm_bytes);
 
 /* A speculative start that falls inside a long blank-free token (a URL) would invent

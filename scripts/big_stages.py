@@ -24,7 +24,6 @@ with datok_amd.Batch(len(text), n_docs) as b:
     b.set_input(text, off)
     for _ in range(int(os.environ.get("WARM_RUNS", "6"))):  # (the model learns its hot cells from the first runs)
         b.run(tok, 256); tot = b.totals()
-    print("hot cells:", tok.hot_stats())
     b.set_profiling(True); b.run(tok, 256); st = b.stage_ms(); b.set_profiling(False)
     total_us = sum(st.values()) * 1e3
     print("%d x 16 MiB, %d lanes, chunk %d, repairs %d: per 16 MiB, us: %s | sum %.1f us = %.1f GB/s" % (
