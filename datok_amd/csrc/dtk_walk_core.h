@@ -886,8 +886,11 @@ __device__ __forceinline__ void add_steps(unsigned long long *counter, uint32_t 
 }
 
 // the lanes' windows of the symbol stream and, for the lean loop, the model's code table (one wave per block)
+#ifndef DTK_ROW_PAD
+#define DTK_ROW_PAD 0u  // bytes between the lanes' rows of codes.  (8 until round 3, to stagger the banks: without them a wave's LDS is 5728 B at 128-byte chunks and seven waves per SIMD fit a CU; the conflicts of the one-byte reads cost nothing measurable: walk 53.8 -> 51.9 us saturated)
+#endif
 #define DTK_WINDOWS(TRANS, SYM)                                                                       \
-  constexpr uint32_t WIN_ROW_ = TRANS::LEAN ? (DTK_WIN8 + 8u) / 2u : DTK_WIN_ROW;                     \
+  constexpr uint32_t WIN_ROW_ = TRANS::LEAN ? (DTK_WIN8 + DTK_ROW_PAD) / 2u : DTK_WIN_ROW;            \
   __shared__ uint16_t s_win[WAVE * WIN_ROW_];                                                         \
   __shared__ uint16_t s_lut[TRANS::LEAN ? 256 : 1];                                                   \
   uint16_t *win_row = s_win + threadIdx.x * WIN_ROW_;                                                 \
