@@ -13,7 +13,7 @@ cases = [("bench de", "tokenizer_de.matok", lambda s: corpus.german_docs(4096, 4
 for name, model, gen in cases:
     tok = datok_amd.load_tokenizer_file(os.path.join(M, model))
     inputs = [gen(2 + k) for k in range(3)]
-    for warm in (16, 8, 4):
+    for warm in (8, 4, 2, 0):
         bs = []
         for t, o in inputs:
             b = datok_amd.Batch(len(t), len(o) - 1)
