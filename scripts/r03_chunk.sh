@@ -1,7 +1,7 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-for c in 128 112 104 96; do
- for w in 16 8; do
+for c in 128 120 112 104; do
+ for w in 8; do
   python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-e2e --parity-docs 32 --chunk $c --warm $w 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
