@@ -944,8 +944,8 @@ __global__ __launch_bounds__(SCAN1_TB) void k_scan3(const uint64_t *ca, const ui
 //
 // One launch behind the compaction: every selected result array goes to its page-locked host buffer (DtkToHostArgs).
 // Sources and destinations are 16-byte aligned (hipMalloc / hipHostMalloc); a wave writes 1 KiB of consecutive bytes
-// per instruction -- posted writes over the link, nothing waits for them but the end of the wave.  The last block
-// to finish (one counter add per block) ... is not needed: the host only looks after the stream's event.
+// per instruction -- posted writes over the link.  The host only looks after the stream's event (`done` tells whether
+// the copy was made at all: not when a count exceeds its buffer or documents are still to be repaired).
 // The kernel must not get in the way of the walks of other batches: with 2048 waves storing as fast as they could the
 // stores queued up in every CU's memory pipeline and a k_spec_both beside it took 0.49 instead of 0.13 ms.  So few
 // waves (one per block, spread over the CUs), each with ONE 1 KiB store instruction in flight: 128 KiB under way on
