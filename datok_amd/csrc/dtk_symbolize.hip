@@ -186,9 +186,10 @@ __global__ __launch_bounds__(SYM_THREADS) void k_symbolize(const uint8_t *__rest
       const unsigned long long lt = lanemask_lt();
       uint32_t slot = qn + popc(b0 & lt) + 2u * popc(b1 & lt) + 4u * popc(b2 & lt) + 8u * popc(b3 & lt);
       qn += popc(b0) + 2u * popc(b1) + 4u * popc(b2) + 8u * popc(b3);
-#pragma unroll
-      for (int j = 0; j < 8; j++)
-        if (rare & (1u << j)) s_q[slot++] = (uint16_t)(i0 + j);
+      // (a loop over the lane's set bits -- as many rounds as the lane with the most bytes >= 0x80 has, two or three in
+      //  European text -- instead of eight conditional stores: 22.1 -> 21.6 us per 16 MiB saturated)
+      for (uint32_t m = rare; __builtin_amdgcn_ballot_w64(m != 0u) != 0ull; m &= m - 1u)
+        if (m) s_q[slot++] = (uint16_t)(i0 + (uint32_t)__builtin_ctz(m));
     };
     const bool full_block = n_here == SYM_BLOCK_BYTES && sym16;  // wave-uniform
 #pragma unroll 1
