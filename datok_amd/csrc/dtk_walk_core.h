@@ -666,7 +666,7 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const Dtk
     en = DTK_ENTRY(pn0);
   }
 #ifdef DTK_PROBE
-  unsigned long long pr_wait = 0, pr_t0 = clock64(), pr_n = 0;
+  unsigned long long pr_wait = 0, pr_t0 = clock64(), pr_n = 0, pr_refill = 0, pr_nrefill = 0;
 #endif
   while (!done) {
     // (the lookup cap as a budget counted down: the borrow of the subtraction is the test -- one instruction, not two)
@@ -704,8 +704,16 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const Dtk
       const uint32_t pn_n = p_n + ((e_n >> DTK_SYM_W_SHIFT) & 7u);
       uint32_t iw = pn_n - wb7;
       if (__builtin_amdgcn_ballot_w64(iw >= DTK_WIN8) != 0ull) {  // also a backtrack to before the window
+#ifdef DTK_PROBE
+        const unsigned long long r0_ = clock64();
+#endif
         DTK_REFILL(pn_n)
         iw = pn_n - wb7;
+#ifdef DTK_PROBE
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        pr_refill += clock64() - r0_;
+        pr_nrefill++;
+#endif
       }
       code_n = row[iw];
     }
@@ -839,8 +847,8 @@ __device__ __forceinline__ void walk_fused(const MatrixFusedTrans &tr, const Dtk
     if (MODE == MODE_CHUNK && lane_id() == 0) {
       atomicAdd(&g_probe[0], wmax); atomicAdd(&g_probe[1], tot_); atomicAdd(&g_probe[2], nmax); atomicAdd(&g_probe[3], 1ull);
     }
-    if (MODE == MODE_START && lane_id() == 0) {
-      atomicAdd(&g_probe[4], wmax); atomicAdd(&g_probe[5], tot_); atomicAdd(&g_probe[6], nmax); atomicAdd(&g_probe[7], 1ull);
+    if (MODE == MODE_CHUNK && lane_id() == 0) {  // the wave's refills of the lanes' windows (uniform: the branch is)
+      atomicAdd(&g_probe[4], pr_refill); atomicAdd(&g_probe[5], pr_nrefill);
     }
   }
 #endif

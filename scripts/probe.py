@@ -35,7 +35,10 @@ for i in range(R):
 dt = time.perf_counter() - t0
 lib.dtk_probe_read(out, 1)
 v = list(out)
-for name, (w, tot, it, waves) in (("chunk", v[0:4]), ("warm-up", v[4:8])):
+if v[3]:
+    print("window refills: %.1f per wave (of %.1f iterations), %.0f cycles each, %.0f cycles per wave" % (
+        v[5] / v[3], v[2] / v[3], v[4] / max(v[5], 1), v[4] / v[3]))
+for name, (w, tot, it, waves) in (("chunk", v[0:4]),):
     if waves:
         print("%-8s waves %d  iterations/wave %.1f  loop cycles/wave %.0f  cycles/iteration %.0f  of which waiting %.0f (%.0f %%)" % (
             name, waves // (R * n), it / waves, tot / waves, tot / max(it, 1), w / max(it, 1), 100.0 * w / max(tot, 1)))
