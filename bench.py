@@ -166,6 +166,8 @@ def e2e_only(args):
                 res = bb.result(copy=False)   # host pointers into the slice's page-locked buffers
                 if fields & B.R_TOK_RUNE:
                     done[1] += int(res.tok_rend[-1]) + int(res.tok_off[-1])
+                if fields & B.R_TOK_RUNE16:
+                    done[1] += int(res.tok_r16[-1, 1]) + int(res.tok_off[-1])
                 if fields & B.R_EVENTS:
                     done[1] += int(res.ev_bits[0, 0]) + int(res.doc_tail[-1])
         pipe.run(tok, pin.array, big_off, RUN_FLAGS, on_slice)      # allocations, lane plans, page-locked buffers
@@ -180,6 +182,8 @@ def e2e_only(args):
         return round(best, 1)
     f_off = B.R_TOK_RUNE | B.R_SENT | B.R_CSR | B.R_STATUS
     f_ev = B.R_EVENTS | B.R_CSR | B.R_STATUS
+    f_off16 = B.R_TOK_RUNE16 | B.R_SENT | B.R_CSR | B.R_STATUS
+    out_bytes_off16 = 4 * (tot["n_tokens"] + tot["n_sent"]) + 28 * n_docs
     out_bytes_off = 4 * (2 * tot["n_tokens"] + tot["n_sent"]) + 28 * n_docs
     h2d = {"h2d_ms": round(h2d_ms, 4), "h2d_GBps": round(total / h2d_ms / 1e6, 2),
            "end_to_end_MBps": run_pipe(0, 3), "slices": n_slices,
@@ -187,6 +191,10 @@ def e2e_only(args):
            "with_results_what": "host text in -> host offsets out: tok_rstart, tok_rend, sent, row offsets and status of "
                                 "every slice copied to page-locked host memory (%.2f B per input byte) under the next "
                                 "slices' upload and walk, read there by the callback; depth 4" % (out_bytes_off / total),
+           "with_results_int16_MBps": run_pipe(f_off16, 4),
+           "with_results_int16_what": "the same with a token's two rune offsets as the int16 halves of one word "
+                                      "(DTK_R_TOK_RUNE16: no document is longer than 32 767 bytes; %.2f B per input byte, "
+                                      "less than the upload)" % (out_bytes_off16 / total),
            "with_event_bitmaps_MBps": run_pipe(f_ev, 4),
            "with_event_bitmaps_what": "the same with the five event bitmaps + tail words instead of the offset arrays "
                                       "(0.63 B per input byte: what a TokenWriter closure replay reads)",

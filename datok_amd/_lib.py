@@ -58,7 +58,7 @@ class ResultView(C.Structure):
                 ("sent", C.c_void_p), ("text_tok_end", C.c_void_p), ("text_sent_end", C.c_void_p),
                 ("status", C.c_void_p), ("ev_bits", C.c_void_p), ("ev_words", C.c_uint64), ("doc_tail", C.c_void_p),
                 ("n_exact", C.c_uint32), ("exact_doc", C.c_void_p), ("exact_off", C.c_void_p),
-                ("calls", C.c_void_p)]
+                ("calls", C.c_void_p), ("tok_r16", C.c_void_p)]
 
 
 SLICE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p)

@@ -987,6 +987,26 @@ extern "C" int dtk_launch_to_host(const DtkToHostArgs *args, void *stream) {
   return (int)hipGetLastError();
 }
 
+// ---- DTK_R_TOK_RUNE16: a token's two rune offsets as the halves of one word (start low), for the way over the link
+__global__ __launch_bounds__(256) void k_pack_r16(const int32_t *__restrict__ rs, const int32_t *__restrict__ re,
+                                                  uint32_t *__restrict__ out, uint64_t n) {
+  const uint64_t i4 = ((uint64_t)blockIdx.x * 256u + threadIdx.x) * 4u;  // (all three arrays are hipMalloc'ed: 16-byte loads)
+  if (i4 + 4u <= n) {
+    const int4 a = *reinterpret_cast<const int4 *>(rs + i4), b = *reinterpret_cast<const int4 *>(re + i4);
+    *reinterpret_cast<uint4 *>(out + i4) =
+        make_uint4(((uint32_t)a.x & 0xFFFFu) | ((uint32_t)b.x << 16), ((uint32_t)a.y & 0xFFFFu) | ((uint32_t)b.y << 16),
+                   ((uint32_t)a.z & 0xFFFFu) | ((uint32_t)b.z << 16), ((uint32_t)a.w & 0xFFFFu) | ((uint32_t)b.w << 16));
+  } else {
+    for (uint64_t i = i4; i < n; i++) out[i] = ((uint32_t)rs[i] & 0xFFFFu) | ((uint32_t)re[i] << 16);
+  }
+}
+
+extern "C" int dtk_launch_pack_r16(const int32_t *rs, const int32_t *re, uint32_t *out, uint64_t n, void *stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_pack_r16, dim3((unsigned)((n + 1023u) / 1024u)), dim3(256), 0, (hipStream_t)stream, rs, re, out, n);
+  return (int)hipGetLastError();
+}
+
 // ---------------------------------------------------------------- launchers
 
 // ---- clears: the accumulator block and the two event arrays of a run in one launch (16-byte stores)

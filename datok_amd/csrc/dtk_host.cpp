@@ -1078,10 +1078,14 @@ struct dtk_batch {
   // asynchronous copies on a stream of their own (dl_stream) -- the batch's own stream is free for the next kernels,
   // the copy engine for the next slice's upload (PCIe is full duplex).  `fields` (DTK_R_*) selects what is copied.
   enum { PB_TOK_OFF, PB_SENT_OFF, PB_TEXT_OFF, PB_RSTART, PB_REND, PB_BSTART, PB_BEND, PB_SENT, PB_TTOK, PB_TSENT,
-         PB_STATUS, PB_BITS, PB_TAIL, PB_N };
+         PB_STATUS, PB_BITS, PB_TAIL, PB_R16, PB_N };
   struct PinBuf { void *p = nullptr; size_t cap = 0; } pin[PB_N];
   PinBuf h_plan;            // staging of the lane plan's tables (plan_lanes)
   uint32_t fields = DTK_R_ALL;
+  uint32_t *d_r16 = nullptr;      // DTK_R_TOK_RUNE16: the packed rune offsets (filled on the download stream)
+  uint64_t r16_cap = 0;
+  uint64_t max_doc_bytes = 0;     // of the current input (what decides whether the narrow form exists)
+  bool max_doc_valid = false;
   hipStream_t dl_stream = nullptr;  // created with the first download, unless the caller lends one (a pipeline's slices share one:
   bool dl_own = false;              //  the runtime maps streams onto four hardware queues, and streams that share a queue serialise)
   hipEvent_t ev_ran = nullptr;      // behind the last launch of dtk_batch_run (dtk_batch_done)
@@ -1210,7 +1214,7 @@ extern "C" void dtk_batch_free(dtk_batch *b) {
                   b->d_csr, b->d_rstart, b->d_rend, b->d_sent,
                   b->d_bstart, b->d_bend, b->d_ttok, b->d_tsent,
                   b->d_sbefore, b->d_ts_end, b->d_doc_ns, b->d_scan_ws, b->d_rws, b->d_out_off, b->d_out,
-                  b->d_exact_ids, b->d_exact_cnt, b->d_exact_off, b->d_calls};
+                  b->d_exact_ids, b->d_exact_cnt, b->d_exact_off, b->d_calls, b->d_r16};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (b->h_totals) (void)hipHostFree(b->h_totals);
@@ -1278,6 +1282,7 @@ extern "C" int dtk_batch_set_input(dtk_batch *b, const uint8_t *text, const uint
   if (!same) {
     b->h_doc_off.assign(doc_off, doc_off + n_docs + 1);
     b->plan_valid = false;
+    b->max_doc_valid = false;
   }
   return DTK_OK;
 }
@@ -1299,6 +1304,7 @@ extern "C" int dtk_batch_set_input_device(dtk_batch *b, const void *d_text, cons
     if (b->h_doc_off[d + 1] < b->h_doc_off[d] || b->h_doc_off[d + 1] - b->h_doc_off[d] >= 0x7FFFFFF0ull)
       return DTK_E_ARG;
   b->plan_valid = false;
+  b->max_doc_valid = false;
   return DTK_OK;
 }
 
@@ -1928,6 +1934,7 @@ extern "C" int dtk_batch_result_device(dtk_batch *b, dtk_result_view *o) {
   if (!b || !o) return DTK_E_ARG;
   int rc = finish(b);
   if (rc != DTK_OK) return rc;
+  o->tok_r16 = nullptr;  // (host results only)
   o->tok_off = b->d_tok_off; o->sent_off = b->d_sent_off; o->text_off = b->d_text_off;
   const bool no_rune = (b->last_flags & DTK_NO_RUNE_OFFSETS) != 0, no_byte = (b->last_flags & DTK_NO_BYTE_OFFSETS) != 0;
   o->tok_rstart = no_rune ? nullptr : b->d_rstart; o->tok_rend = no_rune ? nullptr : b->d_rend;
@@ -1940,7 +1947,7 @@ extern "C" int dtk_batch_result_device(dtk_batch *b, dtk_result_view *o) {
 }
 
 extern "C" int dtk_batch_set_result_fields(dtk_batch *b, uint32_t fields) {
-  if (!b || (fields & ~(uint32_t)(DTK_R_ALL | DTK_R_EAGER))) return DTK_E_ARG;
+  if (!b || (fields & ~(uint32_t)(DTK_R_ALL | DTK_R_TOK_RUNE16 | DTK_R_EAGER))) return DTK_E_ARG;
   b->fields = fields;
   return DTK_OK;
 }
@@ -2022,8 +2029,19 @@ extern "C" int dtk_batch_download_begin(dtk_batch *b) {
   int rc = finish(b);
   if (rc != DTK_OK) return rc;
 
-  uint32_t sel = b->fields & DTK_R_ALL;
-  if (b->last_flags & DTK_NO_RUNE_OFFSETS) sel &= ~(uint32_t)DTK_R_TOK_RUNE;  // (not written by this run)
+  uint32_t sel = b->fields & (DTK_R_ALL | DTK_R_TOK_RUNE16);
+  if (sel & DTK_R_TOK_RUNE16) {
+    // the narrow form holds every offset of a document of at most 32 767 bytes; a batch with a longer one gets the
+    // 32-bit arrays in its place
+    if (!b->max_doc_valid) {
+      uint64_t m = 0;
+      for (uint32_t d = 0; d < b->n_docs; d++) m = std::max(m, b->h_doc_off[d + 1] - b->h_doc_off[d]);
+      b->max_doc_bytes = m;
+      b->max_doc_valid = true;
+    }
+    if (b->max_doc_bytes > 32767u) sel = (sel & ~(uint32_t)DTK_R_TOK_RUNE16) | DTK_R_TOK_RUNE;
+  }
+  if (b->last_flags & DTK_NO_RUNE_OFFSETS) sel &= ~(uint32_t)(DTK_R_TOK_RUNE | DTK_R_TOK_RUNE16);  // (not written by this run)
   if (b->last_flags & DTK_NO_BYTE_OFFSETS) sel &= ~(uint32_t)DTK_R_TOK_BYTE;
   if (b->dl_begun && (b->dl_fields & sel) == sel) return DTK_OK;
   const uint32_t want = sel & ~(b->dl_begun ? b->dl_fields : 0u);
@@ -2036,6 +2054,17 @@ extern "C" int dtk_batch_download_begin(dtk_batch *b) {
     return DTK_OK;
   };
   // (the large arrays first: the small ones ride behind them)
+  if ((want & DTK_R_TOK_RUNE16) && nt) {
+    // packed on the download stream itself, in front of its copy: the batch's stream is idle (finish()) and stays free
+    if (b->r16_cap < b->tok_cap) {
+      if (b->d_r16) HIP_TRY(hipFree(b->d_r16));
+      b->d_r16 = nullptr; b->r16_cap = 0;
+      HIP_TRY(hipMalloc((void **)&b->d_r16, std::max<uint64_t>(b->tok_cap, 4) * 4));
+      b->r16_cap = b->tok_cap;
+    }
+    if (dtk_launch_pack_r16(b->d_rstart, b->d_rend, b->d_r16, nt, b->dl_stream)) return hip_fail(hipGetLastError(), "pack r16");
+    if ((rc = get(dtk_batch::PB_R16, b->d_r16, nt * 4))) return rc;
+  }
   if (want & DTK_R_TOK_RUNE) {
     if ((rc = get(dtk_batch::PB_RSTART, b->d_rstart, nt * 4))) return rc;
     if ((rc = get(dtk_batch::PB_REND, b->d_rend, nt * 4))) return rc;
@@ -2088,6 +2117,7 @@ extern "C" int dtk_batch_result_host(dtk_batch *b, dtk_result_view *o) {
   o->ev_bits = (const uint32_t *)at(dtk_batch::PB_BITS, DTK_R_EVENTS);
   o->ev_words = b->bit_words;
   o->doc_tail = (const uint32_t *)at(dtk_batch::PB_TAIL, DTK_R_EVENTS);
+  o->tok_r16 = (const uint32_t *)at(dtk_batch::PB_R16, DTK_R_TOK_RUNE16);
   o->n_exact = (uint32_t)b->h_exact_ids.size();
   o->exact_doc = b->h_exact_ids.data(); o->exact_off = b->h_exact_off.data(); o->calls = (const dtk_call *)b->h_calls.data();
   return DTK_OK;

@@ -321,6 +321,7 @@ struct DtkToHostArgs {
 extern "C" {
 #endif
 int dtk_launch_to_host(const struct DtkToHostArgs *args, void *stream);
+int dtk_launch_pack_r16(const int32_t *rs, const int32_t *re, uint32_t *out, uint64_t n, void *stream);
 // launchers (dtk_symbolize / dtk_walk / dtk_repair / dtk_compact .hip); stream is a hipStream_t
 int dtk_launch_symbolize(const uint8_t *text, const uint64_t *doc_off, uint32_t n_docs,
                          uint64_t total, const struct DtkSigmaDev *sig, void *sym, int padded,

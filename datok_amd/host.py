@@ -296,7 +296,8 @@ def event_bit(doc_off_d, d):
 class BatchResult:
     """Host copy of dtk_result_view (CSR over documents)."""
     __slots__ = ("tok_off", "sent_off", "text_off", "tok_rstart", "tok_rend", "tok_bstart",
-                 "tok_bend", "sent", "text_tok_end", "text_sent_end", "status", "ev_bits", "doc_tail", "doc_off", "exact")
+                 "tok_bend", "sent", "text_tok_end", "text_sent_end", "status", "ev_bits", "doc_tail", "doc_off", "exact",
+                 "tok_r16")
 
     def events(self, d):
         """Flag byte per cursor position of document d (event_bytes()), for replays."""
@@ -308,7 +309,10 @@ class BatchResult:
         a, b = int(self.tok_off[d]), int(self.tok_off[d + 1])
         s0, s1 = int(self.sent_off[d]), int(self.sent_off[d + 1])
         t0, t1 = int(self.text_off[d]), int(self.text_off[d + 1])
-        return dict(tok_rstart=self.tok_rstart[a:b], tok_rend=self.tok_rend[a:b],
+        rs, re = self.tok_rstart[a:b], self.tok_rend[a:b]
+        if len(self.tok_r16) and not len(self.tok_rstart):  # (R_TOK_RUNE16: int16 pairs {start, end})
+            rs, re = self.tok_r16[a:b, 0].astype(np.int32), self.tok_r16[a:b, 1].astype(np.int32)
+        return dict(tok_rstart=rs, tok_rend=re,
                     tok_bstart=self.tok_bstart[a:b], tok_bend=self.tok_bend[a:b],
                     sent=self.sent[s0:s1], text_tok_end=self.text_tok_end[t0:t1],
                     text_sent_end=self.text_sent_end[t0:t1], status=int(self.status[d]))
@@ -414,6 +418,8 @@ class Batch:
 
     # dtk_batch_set_result_fields (datok_gpu.h DTK_R_*)
     R_CSR, R_TOK_RUNE, R_TOK_BYTE, R_SENT, R_TEXTS, R_STATUS, R_EVENTS, R_ALL = 1, 2, 4, 8, 16, 32, 64, 127
+    R_TOK_RUNE16 = 128   # the rune offsets as int16 pairs (BatchResult.tok_r16); a batch with a document longer than
+                         # 32 767 bytes gets tok_rstart / tok_rend in their place
 
     def set_result_fields(self, fields=R_ALL):
         """Which arrays result() brings to the host (the others come back empty)."""
@@ -451,6 +457,7 @@ class Batch:
         r.status = arr(v.status, nd, np.uint32)
         r.ev_bits = arr(v.ev_bits, 5 * int(v.ev_words), np.uint32).reshape(5, -1) if v.ev_bits else np.zeros((5, 0), np.uint32)
         r.doc_tail = arr(v.doc_tail, nd, np.uint32)
+        r.tok_r16 = arr(v.tok_r16, 2 * t["n_tokens"], np.int16).reshape(-1, 2)
         r.doc_off = self._doc_off
         r.exact = _exact_calls(v, arr)   # documents walked by the exact pass: id -> calls in order
         return r

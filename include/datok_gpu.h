@@ -250,6 +250,8 @@ typedef struct {
   const uint32_t *exact_doc;
   const uint64_t *exact_off; /* n_exact + 1 */
   const dtk_call *calls;
+  /* DTK_R_TOK_RUNE16 (host results only): (uint16_t)tok_rstart[i] | (uint32_t)(uint16_t)tok_rend[i] << 16, or NULL */
+  const uint32_t *tok_r16;
 } dtk_result_view;
 int dtk_batch_result_device(dtk_batch *b, dtk_result_view *out);
 /* status words of the first n documents, copied to the caller's array */
@@ -273,6 +275,12 @@ enum {
   DTK_R_STATUS = 32,   /* status */
   DTK_R_EVENTS = 64,   /* ev_bits, doc_tail */
   DTK_R_ALL = 127,
+  /* tok_r16: the rune offsets of a token as the two halves of one 32-bit word -- start in the low half, end in the
+   * high half, both int16 -- half the bytes of tok_rstart / tok_rend on the link (the download is the longer leg of a
+   * host-to-host pass: 1.2 B per input byte against 1 B of upload).  Offsets never exceed a document's length, so the
+   * narrow form exists when no document of the batch is longer than 32 767 bytes; for a batch with a longer one
+   * tok_r16 comes back NULL and tok_rstart / tok_rend are delivered in its place.  Not part of DTK_R_ALL. */
+  DTK_R_TOK_RUNE16 = 128,
   /* with any of the above: the selected arrays leave for the host inside dtk_batch_run -- a kernel behind the
    * compaction reads the row counts on the device and streams the rows into the batch's page-locked buffers, so no
    * host round trip stands between the walk and the copy.  dtk_batch_result_host then finds them there (a run that

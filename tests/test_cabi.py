@@ -80,3 +80,26 @@ def test_library_never_reads_the_environment():
     assert L.dtk_debug_configure(b"DATOK_NO_SUCH_SWITCH", b"1") == _lib.E_ARG
     assert L.dtk_debug_configure(b"WARM_WS", b"0") == _lib.OK          # (its default: nothing changes)
     assert L.dtk_debug_configure(b"DATOK_WARM_MIN", b"0") == _lib.OK
+
+
+def test_python_structs_mirror_the_header(tmp_path):
+    """The ctypes structures of datok_amd/_lib.py against the C compiler's layout of include/datok_gpu.h: a member
+    added to the header and not to the mirror makes the library write behind the Python object."""
+    import subprocess
+    from datok_amd import _lib
+    pairs = {"dtk_result_view": _lib.ResultView, "dtk_totals": _lib.Totals, "dtk_render_view": _lib.RenderView}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "datok_gpu.h"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        src.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            src.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    src.append("return 0; }")
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(c)])
+    got = dict(l.split() for l in subprocess.check_output([str(exe)]).decode().splitlines())
+    for cname, cls in pairs.items():
+        assert int(got[cname]) == ctypes.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got["%s.%s" % (cname, fname)]) == getattr(cls, fname).offset, (cname, fname)

@@ -242,6 +242,11 @@ def test_newline_after_eot_fires_again_at_offset_zero(tmp_path, kind):
             for _ in range(2):
                 b.run(tok, NEWLINE_AFTER_EOT)
                 assert assert_batch_equals_oracle(om, b.result(), text, off, NEWLINE_AFTER_EOT) >= 5
+            # the offset -1 of that first token in the narrow form of the rune offsets (DTK_R_TOK_RUNE16)
+            b.set_result_fields(datok_amd.Batch.R_ALL | datok_amd.Batch.R_TOK_RUNE16)
+            r = b.result()
+            assert int(r.tok_rstart.min()) == (-1 if kind == "matok" else 0) and r.tok_r16.dtype == np.int16
+            assert np.array_equal(r.tok_r16[:, 0], r.tok_rstart) and np.array_equal(r.tok_r16[:, 1], r.tok_rend)
 
 
 # the automata scripts/fuzz_automata.py found a fault with (seed -> what it was), plus a few that never failed

@@ -891,6 +891,62 @@ def test_result_fields_select_what_comes_to_the_host(gpu, oracle_models):
 
 
 @pytest.mark.gpu
+def test_rune_offsets_as_int16_pairs(gpu, oracle_models):
+    """DTK_R_TOK_RUNE16: a token's rune offsets as the halves of one word -- half the bytes on the link.  Equal to the
+    oracle's offsets (the -1 of token_writer.go:66-68 included); a batch with a document longer than 32 767 bytes gets
+    the 32-bit arrays in its place; alone, in a pipeline, and beside the 32-bit arrays."""
+    import datok_amd
+    from datok_amd import corpus
+    B = datok_amd.Batch
+    tok, om = gpu("tokenizer_de.matok"), oracle_models("tokenizer_de.matok")
+    docs = [b"\nThis.\n\x04\nAnd.\n\x04\n", b"", b"Tree\n\x04\n"]
+    t0, o0 = corpus.german_rich_docs(400, 1200, seed=31)
+    docs += [t0[int(o0[d]):int(o0[d + 1])].tobytes() for d in range(400)]
+    text, off = corpus.concat_docs(docs)
+    narrow = B.R_TOK_RUNE16 | B.R_SENT | B.R_CSR | B.R_STATUS | B.R_TEXTS
+    for flags in (0, 16, 256 | 512):
+        with B(len(text), len(docs)) as b:
+            b.set_input(text, off)
+            b.set_result_fields(narrow)
+            for _ in range(2):
+                b.run(tok, flags)
+                r = b.result()
+                assert r.tok_r16.shape == (b.totals()["n_tokens"], 2) and len(r.tok_rstart) == 0 and len(r.tok_bstart) == 0
+                assert_batch_equals_oracle(om, r, text, off, flags & 16, fields=("tok_rstart", "tok_rend", "sent", "text_tok_end",
+                                                                                "text_sent_end"))
+            b.set_result_fields(narrow | B.R_TOK_RUNE)  # both forms of the same run
+            r = b.result()
+            assert np.array_equal(r.tok_r16[:, 0].astype(np.int32), r.tok_rstart) and np.array_equal(r.tok_r16[:, 1].astype(np.int32), r.tok_rend)
+    # a document of 40 000 bytes: its offsets do not fit
+    long_text, long_off = corpus.concat_docs([docs[5] * 40, docs[6], (docs[7] + b" ") * 60][:3])
+    assert int(np.diff(long_off.astype(np.int64)).max()) > 32767
+    with B(len(long_text), 3) as b:
+        b.set_input(long_text, long_off)
+        b.set_result_fields(narrow)
+        b.run(tok, 0)
+        r = b.result()
+        assert r.tok_r16.shape[0] == 0 and len(r.tok_rstart) == b.totals()["n_tokens"]
+        assert_batch_equals_oracle(om, r, long_text, long_off, fields=("tok_rstart", "tok_rend", "sent"))
+        b.run(tok, 256 | 1024)                     # DTK_NO_RUNE_OFFSETS: neither form
+        r = b.result()
+        assert r.tok_r16.shape[0] == 0 and len(r.tok_rstart) == 0
+    # slices of a pipeline
+    seen = [0]
+
+    def on_slice(first, n, b):
+        r = b.result(copy=False)
+        assert r.tok_r16.shape[0] == b.totals()["n_tokens"] and len(r.tok_rstart) == 0
+        sub_off = (off[first:first + n + 1] - off[first]).astype(np.uint64)
+        assert_batch_equals_oracle(om, r, text[int(off[first]):int(off[first + n])], sub_off, docs=range(0, n, 5),
+                                   fields=("tok_rstart", "tok_rend", "sent"))
+        seen[0] += n
+    with datok_amd.Pipeline(1 << 17, 128, depth=3) as p:
+        p.set_result_fields(narrow)
+        p.run(tok, text, off, 256 | 512, on_slice)
+    assert seen[0] == len(docs)
+
+
+@pytest.mark.gpu
 def test_pipeline_survives_a_failing_callback(gpu):
     """a callback that raises must not leave a Batch view that owns the pipeline's batch (the view's
     __del__ would free it a second time).  The pipeline is used again and closed afterwards."""
