@@ -44,10 +44,12 @@ for seed in range(first, first + n_seeds):
     depth = int(rng.integers(1, 6))
     run_flags = [0, 16, 256, 256 | 512, 256 | 1024][int(rng.integers(0, 5))]
     fields_all = [0, B.R_ALL, B.R_TOK_RUNE | B.R_SENT | B.R_CSR | B.R_STATUS | B.R_TEXTS,
-                  B.R_TOK_BYTE | B.R_SENT | B.R_CSR | B.R_STATUS | B.R_TEXTS | B.R_EVENTS][int(rng.integers(0, 4))]
+                  B.R_TOK_BYTE | B.R_SENT | B.R_CSR | B.R_STATUS | B.R_TEXTS | B.R_EVENTS,
+                  B.R_TOK_RUNE16 | B.R_SENT | B.R_CSR | B.R_STATUS | B.R_TEXTS,   # (int16 pairs, or the 32-bit arrays if a document is long)
+                  B.R_TOK_RUNE16 | B.R_ALL][int(rng.integers(0, 6))]
     cmp_fields = tuple(f for f in ("tok_rstart", "tok_rend", "tok_bstart", "tok_bend", "sent", "text_tok_end", "text_sent_end")
                        if not ((run_flags & 512) and f.startswith("tok_b")) and not ((run_flags & 1024) and f.startswith("tok_r"))
-                       and (fields_all in (0, B.R_ALL) or not (f.startswith("tok_r") and not fields_all & B.R_TOK_RUNE)
+                       and (fields_all in (0, B.R_ALL) or not (f.startswith("tok_r") and not fields_all & (B.R_TOK_RUNE | B.R_TOK_RUNE16))
                             and not (f.startswith("tok_b") and not fields_all & B.R_TOK_BYTE)))
     seen = [0]
 
