@@ -118,7 +118,7 @@ static int deliver(dtk_pipeline *p, uint32_t slot, dtk_slice_fn fn, void *user) 
   const uint32_t first = p->first[slot], n = p->count[slot];
   p->count[slot] = 0;
   p->touched[slot] = 0;
-  if (rc != DTK_OK) return rc;
+  if (rc != DTK_OK) { (void)dtk_batch_sync(p->slots[slot]); return rc; }  // (no copy from the caller's text outlives the call)
   return fn ? fn(user, first, n, p->slots[slot]) : DTK_OK;
 }
 
